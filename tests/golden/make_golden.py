@@ -1,0 +1,330 @@
+"""Generate the golden fixtures in this directory by RUNNING THE REFERENCE.
+
+Run once, in the development container only (needs the reference checkout at
+/root/reference; numpy >= 2 promotion rules are part of the pinned semantics):
+
+    python tests/golden/make_golden.py
+
+Outputs (all data, no code):
+    fake_table.npz   table of (policy probs, value) rows for the fake network
+    game_tier.npz    positions -> ordered legal actions, masks, encodings, results
+    tree_tier.npz    per-root child statistics after S simulations, tree reuse,
+                     noisy roots with the recorded Dirichlet draws
+    selfplay_tier.npz  execute_parallel_episodes stream with recorded RNG draws
+    nn_tier.npz      float32 logits of seeded AlphaZeroNet instances
+"""
+import os
+import random
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))          # tests/
+sys.path.insert(0, "/root/reference")
+
+from src.game import BreakthroughGame, WHITE, BLACK  # noqa: E402
+from src.mcts import MCTS, Node                      # noqa: E402
+from src.model import AlphaZeroNet                   # noqa: E402
+import src.parallel_trainer as ref_pt                # noqa: E402
+
+import fake_net                                      # noqa: E402
+
+
+def game_bits(g):
+    w = b = 0
+    for r in range(8):
+        for c in range(8):
+            if g.board[r, c] == WHITE:
+                w |= 1 << (r * 8 + c)
+            elif g.board[r, c] == BLACK:
+                b |= 1 << (r * 8 + c)
+    return w, b
+
+
+def game_from_bits(w, b, turn, winner=None):
+    board = np.zeros((8, 8), np.int8)
+    for sq in range(64):
+        if (w >> sq) & 1:
+            board[sq // 8, sq % 8] = WHITE
+        elif (b >> sq) & 1:
+            board[sq // 8, sq % 8] = BLACK
+    g = BreakthroughGame(board=board, turn=turn)
+    g._winner = winner
+    return g
+
+
+# ------------------------------------------------------------------ table
+def make_table(T=128):
+    rs = np.random.RandomState(1234)
+    logits = (rs.standard_normal((T, 192)) * 2.0).astype(np.float32)
+    wl = (rs.standard_normal((T, 2)) * 1.0).astype(np.float32)
+    probs = torch.softmax(torch.tensor(logits), dim=1).numpy()
+    wlp = torch.softmax(torch.tensor(wl), dim=1).numpy()
+    values = wlp[:, 0] - wlp[:, 1]
+    # a few degenerate rows: all mass on never-legal actions (168..191 are moves
+    # from the far row) so that the legal prior sum underflows to exactly 0 and
+    # the uniform fallback of _expand_node (mcts.py:277-278) is exercised
+    for r in (5, 77):
+        probs[r] = 0
+        probs[r, 190] = 1.0
+    np.savez(os.path.join(HERE, "fake_table.npz"), probs=probs.astype(np.float32),
+             values=values.astype(np.float32))
+
+
+class TableMCTS(MCTS):
+    """Reference MCTS with only the network call replaced by the table."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.table = fake_net.TableEvaluator()
+
+    def _batch_evaluate(self, games):
+        if not games:
+            return []
+        states = np.array([g.get_encoded_state() for g in games])
+        probs, values = self.table(states)
+        return list(zip(probs, values))   # rows / np.float32 scalars, as mcts.py:258
+
+
+# ------------------------------------------------------------------ game tier
+def make_game_tier():
+    rng = random.Random(7)
+    rows = []
+
+    def record(g):
+        w, b = game_bits(g)
+        moves = g.get_legal_moves()
+        acts = [g.encode_action(m) for m in moves]
+        res = g.get_result()
+        rows.append(dict(
+            white=w, black=b, turn=g.turn, winner=(g._winner or 0),
+            k=len(acts), actions=acts + [255] * (48 - len(acts)),
+            moves=[list(m) for m in moves] + [[255] * 4] * (48 - len(moves)),
+            mask=np.packbits(g.get_legal_action_mask()),
+            planes=np.packbits(g.get_encoded_state() > 0.5),
+            terminal=int(g.is_terminal()), w=res[0], l=res[1]))
+
+    for _ in range(40):                       # reachable positions, terminal ones included
+        g = BreakthroughGame()
+        record(g)
+        while not g.is_terminal():
+            g.step(rng.choice(g.get_legal_moves()))
+            record(g)
+    rng2 = random.Random(42)                  # sparse boards as tests/test_compatibility.py:49-78
+    for _ in range(20):
+        w = b = 0
+        for sq in range(64):
+            if sq // 8 in (0, 7):
+                continue
+            p = rng2.random()
+            if p < 0.1:
+                w |= 1 << sq
+            elif p < 0.2:
+                b |= 1 << sq
+        for turn in (WHITE, BLACK):
+            record(game_from_bits(w, b, turn))
+    # edge cases: blocked side (no legal moves), single pieces on edges
+    record(game_from_bits(1 << 8, 1 << 16, WHITE))         # white a2 blocked by black a3
+    record(game_from_bits(1 << 8, 1 << 16, BLACK))
+    record(game_from_bits(1 << 15, 1 << 55, WHITE))
+    record(game_from_bits(1 << 15, 1 << 55, BLACK))
+    out = {k: np.array([r[k] for r in rows]) for k in rows[0] if k not in ("white", "black")}
+    out["white"] = np.array([r["white"] for r in rows], dtype=np.uint64)
+    out["black"] = np.array([r["black"] for r in rows], dtype=np.uint64)
+    for k in ("turn", "winner", "terminal"):
+        out[k] = out[k].astype(np.int8)
+    for k in ("k", "actions", "moves"):
+        out[k] = out[k].astype(np.uint8)
+    out["w"] = out["w"].astype(np.float32)
+    out["l"] = out["l"].astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "game_tier.npz"), **out)
+    print("game tier:", len(rows), "positions")
+
+
+# ------------------------------------------------------------------ tree tier
+def root_stats(root):
+    acts = list(root.children.keys())
+    ch = [root.children[a] for a in acts]
+    k = len(acts)
+    pad = 48 - k
+    return dict(
+        k=k, root_N=root.visit_count,
+        actions=np.array(acts + [255] * pad, np.uint8),
+        N=np.array([c.visit_count for c in ch] + [0] * pad, np.uint32),
+        W=np.array([np.float32(c.value_sum) for c in ch] + [0] * pad, np.float32),
+        P=np.array([float(c.prior) for c in ch] + [0] * pad, np.float64),
+        p_is64=np.array([int(not isinstance(c.prior, np.float32)) for c in ch] + [0] * pad, np.uint8))
+
+
+def tree_positions():
+    """Root positions: both colours, opening to late game (terminals in-tree)."""
+    rng = random.Random(11)
+    out = []
+    for plies in (0, 1, 6, 15, 24, 33, 40, 47, 52, 58):
+        while True:
+            g = BreakthroughGame()
+            ok = True
+            for _ in range(plies):
+                if g.is_terminal():
+                    ok = False
+                    break
+                g.step(rng.choice(g.get_legal_moves()))
+            if ok and not g.is_terminal():
+                out.append(g)
+                break
+    return out
+
+
+def make_tree_tier():
+    roots_pos = tree_positions()
+    out = {}
+    wb = [game_bits(g) for g in roots_pos]
+    out["white"] = np.array([x[0] for x in wb], np.uint64)
+    out["black"] = np.array([x[1] for x in wb], np.uint64)
+    out["turn"] = np.array([g.turn for g in roots_pos], np.int8)
+    sims_list = [1, 2, 50, 100, 800]
+    out["sims_list"] = np.array(sims_list)
+    for S in sims_list:                                   # (i) fresh search, noise off
+        m = TableMCTS(None, num_simulations=S, c_puct=1.5)
+        roots = m.search_batch([g.clone() for g in roots_pos], None, add_noise=False)
+        st = [root_stats(r) for r in roots]
+        for key in st[0]:
+            out[f"fresh{S}_{key}"] = np.array([s[key] for s in st])
+    # (ii) reuse sequence: S=100, 14 plies, actions drawn from the T=1 visit distribution
+    for tag, noisy in (("reuse", False), ("noisy", True)):
+        S = 100 if not noisy else 60
+        plies = 14
+        games = [roots_pos[i].clone() for i in (0, 1, 4, 6)]
+        nG = len(games)
+        m = TableMCTS(None, num_simulations=S, c_puct=1.5)
+        roots = [None] * nG
+        rs = np.random.RandomState(99)
+        actions = np.full((plies, nG), 255, np.int16)
+        noise_rec = np.zeros((plies, nG, 48), np.float64)
+        stats = []
+        alive = [True] * nG
+        np.random.seed(2024)
+        orig_dirichlet = np.random.dirichlet
+        for ply in range(plies):
+            idx = [i for i in range(nG) if alive[i]]
+            drawn = []
+
+            def rec_dirichlet(alpha, *a, **k):
+                v = orig_dirichlet(alpha, *a, **k)
+                drawn.append(v)
+                return v
+            np.random.dirichlet = rec_dirichlet
+            try:
+                new_roots = m.search_batch([games[i] for i in idx], [roots[i] for i in idx],
+                                           add_noise=noisy)
+            finally:
+                np.random.dirichlet = orig_dirichlet
+            for j, i in enumerate(idx):
+                roots[i] = new_roots[j]
+                if noisy:
+                    noise_rec[ply, i, :len(drawn[j])] = drawn[j]
+            ply_stats = []
+            for i in range(nG):
+                if not alive[i]:
+                    ply_stats.append(None)
+                    continue
+                ply_stats.append(root_stats(roots[i]))
+                probs = m.get_action_probs(roots[i], temperature=1.0)
+                a = int(rs.choice(192, p=probs.astype(np.float64) / probs.astype(np.float64).sum()))
+                actions[ply, i] = a
+                games[i].step(games[i].decode_action(a))
+                roots[i] = roots[i].children[a] if a in roots[i].children else None
+                if games[i].is_terminal():
+                    alive[i] = False
+            stats.append(ply_stats)
+        out[f"{tag}_sims"] = np.array(S)
+        out[f"{tag}_games"] = np.array([0, 1, 4, 6])
+        out[f"{tag}_played"] = actions
+        if noisy:
+            out[f"{tag}_noise"] = noise_rec
+        empty = dict(k=0, root_N=0, actions=np.full(48, 255, np.uint8), N=np.zeros(48, np.uint32),
+                     W=np.zeros(48, np.float32), P=np.zeros(48, np.float64), p_is64=np.zeros(48, np.uint8))
+        for key in empty:
+            out[f"{tag}_{key}"] = np.array([[(s or empty)[key] for s in ps] for ps in stats])
+    np.savez_compressed(os.path.join(HERE, "tree_tier.npz"), **out)
+    print("tree tier done")
+
+
+# ------------------------------------------------------------------ self-play tier
+def make_selfplay_tier():
+    nG, S = 3, 30
+    tmp = tempfile.mkdtemp()
+    model = AlphaZeroNet(num_blocks=1, num_filters=8)
+    tr = ref_pt.ParallelTrainer(model, device="cpu", num_parallel_games=nG, num_simulations=S,
+                                checkpoint_dir=tmp)
+    tr.mcts = TableMCTS(None, num_simulations=S, c_puct=1.5)
+    dir_draws, choice_draws = [], []
+    od, oc = np.random.dirichlet, np.random.choice
+
+    def rd(alpha, *a, **k):
+        v = od(alpha, *a, **k)
+        dir_draws.append(np.concatenate([v, np.zeros(48 - len(v))]))
+        return v
+
+    def rc(n, *a, **k):
+        v = oc(n, *a, **k)
+        choice_draws.append(int(v))
+        return v
+    np.random.seed(31337)
+    np.random.dirichlet, np.random.choice = rd, rc
+    try:
+        examples = tr.execute_parallel_episodes(nG)
+    finally:
+        np.random.dirichlet, np.random.choice = od, oc
+    np.savez_compressed(
+        os.path.join(HERE, "selfplay_tier.npz"),
+        n_games=np.array(nG), sims=np.array(S),
+        dirichlet=np.array(dir_draws, np.float64), choices=np.array(choice_draws, np.int16),
+        states=np.packbits(np.array([e[0] for e in examples]) > 0.5, axis=None),
+        n_examples=np.array(len(examples)),
+        policies=np.array([e[1] for e in examples], np.float32),
+        wls=np.array([e[2] for e in examples], np.float32))
+    print("selfplay tier:", len(examples), "examples,", len(choice_draws), "moves")
+
+
+# ------------------------------------------------------------------ NN tier
+def randomize_bn(model, seed):
+    """Give every BatchNorm non-trivial statistics, deterministically."""
+    g = torch.Generator().manual_seed(seed)
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            n = mod.num_features
+            mod.running_mean.copy_(torch.randn(n, generator=g) * 0.1)
+            mod.running_var.copy_(torch.rand(n, generator=g) + 0.5)
+            mod.weight.data.copy_(torch.rand(n, generator=g) + 0.5)
+            mod.bias.data.copy_(torch.randn(n, generator=g) * 0.1)
+
+
+def make_nn_tier():
+    d = np.load(os.path.join(HERE, "game_tier.npz"))
+    sel = np.arange(0, len(d["white"]), max(1, len(d["white"]) // 24))[:24]
+    planes = np.unpackbits(d["planes"][sel], axis=1)[:, :192].reshape(-1, 3, 8, 8).astype(np.float32)
+    out = dict(sel=sel, planes=np.packbits(planes > 0.5, axis=None))
+    for tag, blocks, filters in (("small", 2, 32), ("full", 20, 128)):
+        torch.manual_seed(0)
+        net = AlphaZeroNet(num_blocks=blocks, num_filters=filters)
+        randomize_bn(net, 1)
+        net.eval()
+        with torch.no_grad():
+            pl, wl = net(torch.tensor(planes))
+        out[f"{tag}_policy_logits"] = pl.numpy()
+        out[f"{tag}_wl_logits"] = wl.numpy()
+    np.savez_compressed(os.path.join(HERE, "nn_tier.npz"), **out)
+    print("nn tier done")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(4)
+    make_table()
+    make_game_tier()
+    make_tree_tier()
+    make_selfplay_tier()
+    make_nn_tier()

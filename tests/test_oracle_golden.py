@@ -1,0 +1,142 @@
+"""Pins the CPU oracle (oracle/az_oracle.c) to the fixtures that were generated
+by running the reference itself (tests/golden/make_golden.py).  Bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from fake_net import TableEvaluator
+
+
+@pytest.fixture(scope="module")
+def game_tier(golden_dir):
+    return np.load(os.path.join(golden_dir, "game_tier.npz"))
+
+
+@pytest.fixture(scope="module")
+def tree_tier(golden_dir):
+    return np.load(os.path.join(golden_dir, "tree_tier.npz"))
+
+
+def test_game_tier_bit_exact(game_tier):
+    d = game_tier
+    n = len(d["white"])
+    assert n > 2000
+    for i in range(n):
+        p = orc.make_pos(d["white"][i], d["black"][i], d["turn"][i], d["winner"][i])
+        acts = orc.legal_actions(p)
+        k = int(d["k"][i])
+        assert len(acts) == k
+        assert np.array_equal(acts, d["actions"][i][:k])           # order included
+        assert np.array_equal(np.packbits(orc.legal_mask(p)), d["mask"][i])
+        assert np.array_equal(np.packbits(orc.encode_state(p) > 0.5), d["planes"][i])
+        assert orc.is_terminal(p) == bool(d["terminal"][i])
+        assert orc.get_result(p) == (float(d["w"][i]), float(d["l"][i]))
+
+
+def test_step_reproduces_reference_games(game_tier):
+    """Replaying consecutive fixture positions through azo_step_action must give
+    the reference's next position, winner included (game.py:156-187)."""
+    d = game_tier
+    checked = 0
+    for i in range(len(d["white"]) - 1):
+        if d["terminal"][i]:
+            continue
+        p = orc.make_pos(d["white"][i], d["black"][i], d["turn"][i], d["winner"][i])
+        nxt = (d["white"][i + 1], d["black"][i + 1], d["turn"][i + 1], d["winner"][i + 1])
+        if d["turn"][i + 1] != -d["turn"][i]:
+            continue                                   # fixture boundary, not a game step
+        found = False
+        for a in orc.legal_actions(p):
+            q = orc.step_action(p, a)
+            if (q.white, q.black, q.turn, q.winner) == tuple(int(x) for x in nxt):
+                found = True
+                break
+        if found:
+            checked += 1
+    assert checked > 1500
+
+
+def test_batch_status_matches_winner(game_tier):
+    d = game_tier
+    legal3, mask, planes, status = orc.movegen_batch(d["white"], d["black"], d["turn"])
+    reach = np.arange(len(status)) < 2586 if len(status) > 2586 else np.ones(len(status), bool)
+    won = d["winner"] != 0
+    assert np.array_equal(status[won & reach], d["winner"][won & reach])
+    nomoves = (d["k"] == 0) & ~won
+    assert np.all(status[nomoves] == 2)
+    assert np.array_equal(np.packbits(mask.astype(bool), axis=1), d["mask"])
+
+
+def _check_children(st, d, prefix, idx):
+    k = int(d[f"{prefix}_k"][idx])
+    assert st is not None
+    assert len(st["actions"]) == k
+    assert st["root_N"] == int(d[f"{prefix}_root_N"][idx])
+    assert np.array_equal(st["actions"], d[f"{prefix}_actions"][idx][:k])
+    assert np.array_equal(st["N"], d[f"{prefix}_N"][idx][:k])
+    assert np.array_equal(st["W"].view(np.uint32), d[f"{prefix}_W"][idx][:k].view(np.uint32))
+    assert np.array_equal(st["p_is64"], d[f"{prefix}_p_is64"][idx][:k])
+    assert np.array_equal(st["P"].view(np.uint64), d[f"{prefix}_P"][idx][:k].view(np.uint64))
+
+
+@pytest.mark.parametrize("S", [1, 2, 50, 100, 800])
+def test_tree_fresh_search_bit_exact(tree_tier, S):
+    d = tree_tier
+    nG = len(d["white"])
+    ev = TableEvaluator()
+    m = orc.OracleMCTS(nG, c_puct=1.5)
+    for g in range(nG):
+        m.set_game(g, orc.make_pos(d["white"][g], d["black"][g], d["turn"][g]))
+    m.search(ev, S)
+    for g in range(nG):
+        _check_children(m.root_children(g), d, f"fresh{S}", g)
+
+
+@pytest.mark.parametrize("tag", ["reuse", "noisy"])
+def test_tree_reuse_sequence_bit_exact(tree_tier, tag):
+    d = tree_tier
+    games = d[f"{tag}_games"]
+    S = int(d[f"{tag}_sims"])
+    actions = d[f"{tag}_played"]
+    nG = len(games)
+    ev = TableEvaluator()
+    m = orc.OracleMCTS(nG, c_puct=1.5)
+    for j, g in enumerate(games):
+        m.set_game(j, orc.make_pos(d["white"][g], d["black"][g], d["turn"][g]))
+    alive = np.ones(nG, bool)
+    saw64 = False
+    for ply in range(actions.shape[0]):
+        if not alive.any():
+            break
+        m.set_active(alive)
+        noise = d[f"{tag}_noise"][ply] if tag == "noisy" else None
+        m.search(ev, S, noise=noise)
+        for j in range(nG):
+            if not alive[j]:
+                continue
+            st = m.root_children(j)
+            _check_children(st, d, tag, (ply, j))
+            saw64 |= bool(st["p_is64"].any())
+            a = int(actions[ply, j])
+            m.advance(j, a)
+            if orc.is_terminal(m.get_game(j)):
+                alive[j] = False
+    if tag == "noisy":
+        assert saw64
+
+
+def test_selfplay_stream_bit_exact(golden_dir):
+    """execute_parallel_episodes (parallel_trainer.py:137-223) replayed with the
+    recorded Dirichlet draws and sampled actions."""
+    d = np.load(os.path.join(golden_dir, "selfplay_tier.npz"))
+    from selfplay_replay import replay_selfplay_oracle
+    states, policies, wls = replay_selfplay_oracle(
+        int(d["n_games"]), int(d["sims"]), d["dirichlet"], d["choices"], TableEvaluator())
+    n = int(d["n_examples"])
+    ref_states = np.unpackbits(d["states"])[: n * 192].reshape(n, 3, 8, 8).astype(np.float32)
+    assert len(states) == n
+    assert np.array_equal(np.array(states), ref_states)
+    assert np.array_equal(np.array(policies).view(np.uint32), d["policies"].view(np.uint32))
+    assert np.array_equal(np.array(wls), d["wls"])
