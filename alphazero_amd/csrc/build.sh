@@ -1,0 +1,20 @@
+#!/bin/bash
+# Builds alphazero_amd/libazamd.so for gfx950 (cross-compiles without a GPU).
+set -euo pipefail
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+OUT=../libazamd.so
+OBJ=../../build/obj
+mkdir -p "$OBJ"
+COMMON="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-result"
+pids=()
+# tree/movegen: exact float32 semantics -> no FMA contraction
+$HIPCC $COMMON -ffp-contract=off -c tree.hip -o $OBJ/tree.o & pids+=($!)
+$HIPCC $COMMON -ffp-contract=off -c movegen.hip -o $OBJ/movegen.o & pids+=($!)
+for f in net selfplay; do
+  if [ -f $f.hip ]; then $HIPCC $COMMON -c $f.hip -o $OBJ/$f.o & pids+=($!); fi
+done
+g++ -O2 -fPIC -std=c++17 -c core.cpp -o $OBJ/core.o & pids+=($!)
+for p in "${pids[@]}"; do wait $p; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJ/*.o
+echo "built $(readlink -f $OUT)"

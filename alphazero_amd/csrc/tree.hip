@@ -1,0 +1,687 @@
+// PUCT tree search over an SoA node pool in HBM, one wavefront per game.
+//
+// Compile with -ffp-contract=off: the reference evaluates q + u as two
+// separately rounded float32 operations (src/mcts.py:299-305) and visit counts
+// are only bit-exact if this code does the same.
+//
+// Node pool layout (per engine, all arrays [B * cap], game g owns the slice
+// [g*cap, (g+1)*cap)); a node is also the edge from its parent:
+//   N  u32   visit_count            (src/mcts.py:27)
+//   W  f32   value_sum              (float32 in the reference under numpy >= 2)
+//   P  f32   prior                  (src/mcts.py:274-279)
+//   FC u32   index of first child; children are contiguous, in insertion order
+//   IN u32   action | n_child << 8 | flags << 16
+// A game's nodes are bump-allocated; re-rooting moves the root index and a new
+// game resets the allocator.  Noisy root priors (float64 in the reference after
+// src/mcts.py:326) live in a per-game side array of 48 doubles.
+#include <vector>
+
+#include "az_engine.h"
+
+namespace az {
+
+// planes [3][8][8] float32 of a canonical position: 48 lanes x 16 B
+__device__ inline void write_planes(float* dst, uint64_t mine, uint64_t theirs, int lane) {
+    if (lane < 48) {
+        const int p = lane >> 4;
+        const int s0 = (4 * lane) & 63;
+        const uint64_t src = (p == 0) ? mine : ((p == 1) ? theirs : ~0ull);
+        float4 v;
+        v.x = (float)((src >> (s0 + 0)) & 1ull);
+        v.y = (float)((src >> (s0 + 1)) & 1ull);
+        v.z = (float)((src >> (s0 + 2)) & 1ull);
+        v.w = (float)((src >> (s0 + 3)) & 1ull);
+        reinterpret_cast<float4*>(dst)[lane] = v;
+    }
+}
+
+__device__ inline double wave_max_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double other = __shfl_xor(v, o);
+        v = (other > v) ? other : v;
+    }
+    return v;
+}
+
+__device__ inline uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ inline double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// src/mcts.py:117-133
+__global__ __launch_bounds__(64) void k_roots_prepare(EngineView E, float* planes,
+                                                      uint8_t* need_eval) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (!E.active[g]) {
+        if (lane == 0) { E.leaf_need[g] = 0; if (need_eval) need_eval[g] = 0; }
+        return;
+    }
+    const size_t pool = (size_t)g * E.cap;
+    uint32_t r = E.root[g];
+    const bool fresh = (r == NODE_NONE);
+    if (fresh) {                        // Node(0): fresh tree, allocator reset
+        r = 0;
+        if (lane == 0) {
+            E.root[g] = 0; E.used[g] = 1; E.root_mode[g] = 0;
+            E.N[pool] = 0; E.W[pool] = 0.f; E.P[pool] = 0.f; E.FC[pool] = 0; E.IN[pool] = 0;
+        }
+    }
+    const uint32_t k = fresh ? 0 : ((E.IN[pool + r] >> 8) & 0xFF);
+    const int need = (k == 0);
+    if (need) {
+        const uint64_t w = E.white[g], b = E.black[g];
+        const int t = E.turn[g];
+        const uint64_t mine = (t > 0) ? w : bitrev64(b);
+        const uint64_t theirs = (t > 0) ? b : bitrev64(w);
+        if (lane == 0) {
+            E.leaf_node[g] = r; E.leaf_mine[g] = mine; E.leaf_theirs[g] = theirs;
+            E.leaf_turn[g] = (int8_t)t; E.path_len[g] = 1; E.path[(size_t)g * MAX_DEPTH] = r;
+        }
+        if (planes) write_planes(planes + (size_t)g * 192, mine, theirs, lane);
+    }
+    if (lane == 0) { E.leaf_need[g] = (uint8_t)need; if (need_eval) need_eval[g] = (uint8_t)need; }
+}
+
+// ---------------------------------------------------------------------------
+// src/mcts.py:153-171 with _select_child (:281-312)
+__global__ __launch_bounds__(64) void k_select(EngineView E, float* planes, uint8_t* need_eval) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (!E.active[g]) {
+        if (lane == 0) { E.leaf_need[g] = 0; if (need_eval) need_eval[g] = 0; }
+        return;
+    }
+    const size_t pool = (size_t)g * E.cap;
+    const uint32_t r = E.root[g];
+    const int rmode = E.root_mode[g];
+    int t = E.turn[g];
+    int win = E.winner[g];
+    uint64_t mine, theirs;
+    {
+        const uint64_t w = E.white[g], b = E.black[g];
+        mine = (t > 0) ? w : bitrev64(b);
+        theirs = (t > 0) ? b : bitrev64(w);
+    }
+    uint32_t node = r;
+    uint32_t* path = E.path + (size_t)g * MAX_DEPTH;
+    int depth = 1;
+    if (lane == 0) path[0] = node;
+    const float cp32 = (float)E.c_puct;
+    while (true) {
+        const uint32_t inf = E.IN[pool + node];
+        const int k = (inf >> 8) & 0xFF;
+        if (k == 0) break;
+        if (depth >= MAX_DEPTH) { if (lane == 0) atomicOr(E.err, ERR_DEPTH); break; }
+        const uint32_t fc = E.FC[pool + node];
+        const uint32_t pn = E.N[pool + node];
+        const double sqrt_parent = sqrt((double)(pn > 1 ? pn : 1));
+        const bool root64 = (node == r) && rmode;
+        const bool f64mode = root64 || ((inf >> 16) & FLAG_UNIFORM64);
+        double score = -INFINITY;
+        uint32_t cinfo = 0;
+        if (lane < k) {
+            const uint32_t cN = E.N[pool + fc + lane];
+            const float cW = E.W[pool + fc + lane];
+            cinfo = E.IN[pool + fc + lane];
+            if (!f64mode) {
+                const float cP = E.P[pool + fc + lane];
+                const float q = (cN == 0) ? 0.0f : -(cW / (float)cN);
+                float u = cp32 * cP;
+                u = u * (float)sqrt_parent;
+                u = u / (float)(1u + cN);
+                const float s = q + u;
+                score = (double)s;
+            } else {
+                const double p64 = root64 ? E.root_p64[(size_t)g * 48 + lane] : 1.0 / (double)k;
+                const double q = (cN == 0) ? 0.0 : (double)(-(cW / (float)cN));
+                double u = E.c_puct * p64;
+                u = u * sqrt_parent;
+                u = u / (double)(1u + cN);
+                score = q + u;
+            }
+        }
+        // argmax with ties to the lowest child slot (strict '>' in insertion order)
+        const double best = wave_max_f64(score);
+        const unsigned long long tie = __ballot(score == best);
+        const int bl = (tie == 0) ? 0 : (__ffsll((long long)tie) - 1);
+        const int a = __shfl((int)(cinfo & 0xFF), bl);
+        // decode_action + step in canonical coordinates (src/game.py:257-278, 156-187)
+        const int sq = a / 3, d = a - 3 * sq;
+        const int to = sq + ((d == 0) ? 8 : ((d == 1) ? 7 : 9));
+        const uint64_t fb = 1ull << sq, tb = 1ull << (to & 63);
+        mine = (mine & ~fb) | tb;
+        theirs &= ~tb;
+        if (to >= 56) win = t;
+        if (win == 0 && theirs == 0) win = t;
+        const uint64_t nm = bitrev64(theirs), nt = bitrev64(mine);
+        mine = nm; theirs = nt; t = -t;
+        node = fc + bl;
+        if (lane == 0) path[depth] = node;
+        ++depth;
+    }
+    const Legal3 l = legal_sources(mine, theirs);
+    const bool terminal = (win != 0) || ((l.fwd | l.dl | l.dr) == 0);
+    if (lane == 0) {
+        E.leaf_node[g] = node; E.leaf_mine[g] = mine; E.leaf_theirs[g] = theirs;
+        E.leaf_turn[g] = (int8_t)t; E.path_len[g] = (uint16_t)depth;
+        E.leaf_need[g] = terminal ? 0 : 1;
+        // src/mcts.py:328-335: result seen by the side to move at the leaf
+        E.leaf_tv[g] = (win != 0) ? ((win == t) ? 1.0f : -1.0f) : -1.0f;
+        if (need_eval) need_eval[g] = terminal ? 0 : 1;
+        atomicAdd(E.stat_depth, (unsigned long long)(depth - 1));
+    }
+    if (!terminal && planes) write_planes(planes + (size_t)g * 192, mine, theirs, lane);
+}
+
+// ---------------------------------------------------------------------------
+// _expand_node (src/mcts.py:260-279) + _backpropagate (:337-342)
+__global__ __launch_bounds__(64) void k_expand_backup(EngineView E, const float* probs,
+                                                      const float* values, int do_backup) {
+    __shared__ float s_p[MAX_CHILDREN];
+    __shared__ uint8_t s_a[MAX_CHILDREN];
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (!E.active[g]) return;
+    const size_t pool = (size_t)g * E.cap;
+    const int need = E.leaf_need[g];
+    if (need) {
+        const uint64_t mine = E.leaf_mine[g], theirs = E.leaf_theirs[g];
+        const int t = E.leaf_turn[g];
+        const uint32_t leaf = E.leaf_node[g];
+        const Legal3 l = legal_sources(mine, theirs);
+        const int k = __popcll(l.fwd) + __popcll(l.dl) + __popcll(l.dr);
+        // insertion order (src/game.py:117-118 scans the REAL board row-major):
+        // White = ascending canonical squares, Black = descending
+        const int sq = lane;
+        const uint64_t before = (t > 0) ? ((1ull << sq) - 1ull)
+                                        : ((sq == 63) ? 0ull : (~0ull << (sq + 1)));
+        int rank = __popcll(l.fwd & before) + __popcll(l.dl & before) + __popcll(l.dr & before);
+        const float* pr = probs + (size_t)g * 192;
+        if ((l.fwd >> sq) & 1ull) { s_a[rank] = (uint8_t)(sq * 3 + 0); s_p[rank] = pr[sq * 3 + 0]; ++rank; }
+        if ((l.dl >> sq) & 1ull)  { s_a[rank] = (uint8_t)(sq * 3 + 1); s_p[rank] = pr[sq * 3 + 1]; ++rank; }
+        if ((l.dr >> sq) & 1ull)  { s_a[rank] = (uint8_t)(sq * 3 + 2); s_p[rank] = pr[sq * 3 + 2]; ++rank; }
+        __syncthreads();
+        const float p_r = (lane < k) ? s_p[lane] : 0.f;
+        const uint32_t a_r = (lane < k) ? s_a[lane] : 0;
+        float prior_sum = 0.0f;                       // sequential float32 sum, insertion order
+        for (int i = 0; i < k; ++i) prior_sum = prior_sum + __shfl(p_r, i);
+        if (k > 0) {
+            const uint32_t base = E.used[g];
+            if ((uint64_t)base + (uint64_t)k > (uint64_t)E.cap) {
+                if (lane == 0) atomicOr(E.err, ERR_POOL);
+            } else {
+                if (lane < k) {
+                    const size_t c = pool + base + lane;
+                    E.N[c] = 0; E.W[c] = 0.f; E.FC[c] = 0; E.IN[c] = a_r;
+                    E.P[c] = (prior_sum > 0) ? (p_r / prior_sum) : (float)(1.0 / (double)k);
+                }
+                if (lane == 0) {
+                    E.used[g] = base + k;
+                    E.FC[pool + leaf] = base;
+                    const uint32_t flags = (prior_sum > 0) ? 0u : FLAG_UNIFORM64;
+                    E.IN[pool + leaf] = (E.IN[pool + leaf] & 0xFF) | ((uint32_t)k << 8) | (flags << 16);
+                }
+            }
+        }
+    }
+    if (do_backup) {
+        const int len = E.path_len[g];
+        const float v = need ? values[g] : E.leaf_tv[g];
+        const uint32_t* path = E.path + (size_t)g * MAX_DEPTH;
+        for (int i = lane; i < len; i += 64) {
+            const size_t n = pool + path[i];
+            const float vv = ((len - 1 - i) & 1) ? -v : v;   // value = -value per level
+            E.N[n] = E.N[n] + 1;
+            E.W[n] = E.W[n] + vv;
+        }
+        if (lane == 0) atomicAdd(E.stat_descents, 1ull);
+    }
+    if (lane == 0) E.leaf_need[g] = 0;
+}
+
+// ---------------------------------------------------------------------------
+// counter-based generator for the device-drawn Dirichlet noise and move sampling
+__device__ inline uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+struct Rng {
+    uint64_t key, ctr;
+    __device__ Rng(uint64_t seed, uint64_t a, uint64_t b, uint64_t c)
+        : key(mix64(seed ^ mix64(a * 0x9E3779B97F4A7C15ull + b) ^ (c << 32))), ctr(0) {}
+    __device__ uint64_t next() { return mix64(key + 0x9E3779B97F4A7C15ull * (++ctr)); }
+    __device__ double uniform() { return ((double)(next() >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
+    __device__ double normal() {
+        const double u1 = uniform(), u2 = uniform();
+        return sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+    }
+    // Marsaglia-Tsang, boosted for shape < 1
+    __device__ double gamma(double a) {
+        const double boost = (a < 1.0) ? pow(uniform(), 1.0 / a) : 1.0;
+        const double aa = (a < 1.0) ? a + 1.0 : a;
+        const double d = aa - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+        for (int it = 0; it < 64; ++it) {
+            const double x = normal();
+            double v = 1.0 + c * x;
+            if (v <= 0) continue;
+            v = v * v * v;
+            const double u = uniform();
+            if (log(u) < 0.5 * x * x + d - d * v + d * log(v)) return d * v * boost;
+        }
+        return d * boost;
+    }
+};
+
+// _add_dirichlet_noise (src/mcts.py:314-326)
+__global__ __launch_bounds__(64) void k_add_noise(EngineView E, const double* noise,
+                                                  uint64_t call_id) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (!E.active[g]) return;
+    const uint32_t r = E.root[g];
+    if (r == NODE_NONE) return;
+    const size_t pool = (size_t)g * E.cap;
+    const uint32_t inf = E.IN[pool + r];
+    const int k = (inf >> 8) & 0xFF;
+    if (k == 0) return;
+    const uint32_t fc = E.FC[pool + r];
+    double nz;
+    if (noise) {
+        nz = (lane < k) ? noise[(size_t)g * 48 + lane] : 0.0;
+    } else {
+        Rng rng(E.seed, (uint64_t)g, call_id, (uint64_t)lane);
+        const double gm = (lane < k) ? rng.gamma(E.alpha) : 0.0;
+        const double tot = wave_sum_f64(gm);
+        nz = (tot > 0) ? gm / tot : 1.0 / (double)k;
+    }
+    if (lane < k) {
+        const double add = E.eps * nz;
+        double p;
+        if (E.root_mode[g]) {
+            p = (1.0 - E.eps) * E.root_p64[(size_t)g * 48 + lane] + add;
+        } else if ((inf >> 16) & FLAG_UNIFORM64) {
+            p = (1.0 - E.eps) * (1.0 / (double)k) + add;
+        } else {
+            const float keep = (float)(1.0 - E.eps) * E.P[pool + fc + lane];  // float32 product
+            p = (double)keep + add;
+        }
+        E.root_p64[(size_t)g * 48 + lane] = p;
+    }
+    __syncthreads();
+    if (lane == 0) E.root_mode[g] = 1;
+}
+
+// ---------------------------------------------------------------------------
+// get_action_probs (src/mcts.py:191-225), temperature 0 or 1
+__global__ __launch_bounds__(64) void k_action_probs(EngineView E, const float* temps,
+                                                     float* probs_out) {
+    __shared__ float row[192];
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (!E.active[g]) return;
+    const size_t pool = (size_t)g * E.cap;
+    const uint32_t r = E.root[g];
+    int k = 0; uint32_t fc = 0;
+    if (r != NODE_NONE) { k = (E.IN[pool + r] >> 8) & 0xFF; fc = E.FC[pool + r]; }
+    const bool t0 = temps ? (temps[g] == 0.0f) : (E.ply[g] >= E.temp_thr);
+    for (int i = lane; i < 192; i += 64) row[i] = 0.f;
+    __syncthreads();
+    uint32_t cnt = 0; int a = 0;
+    if (lane < k) { cnt = E.N[pool + fc + lane]; a = E.IN[pool + fc + lane] & 0xFF; }
+    const uint32_t total = wave_sum_u32(cnt);
+    if (t0) {
+        // np.argmax over the 192-vector: highest count, lowest action index
+        unsigned long long key = (lane < k) ? (((unsigned long long)cnt << 8) | (unsigned)(255 - a)) : 0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(key, o);
+            key = other > key ? other : key;
+        }
+        const int best = ((key >> 8) == 0) ? 0 : (255 - (int)(key & 0xFF));
+        if (lane == 0) row[best] = 1.0f;
+    } else if (lane < k) {
+        row[a] = (total > 0) ? ((float)cnt / (float)total) : (float)(1.0 / (double)k);
+    }
+    __syncthreads();
+    for (int i = lane; i < 192; i += 64) probs_out[(size_t)g * 192 + i] = row[i];
+}
+
+// ---------------------------------------------------------------------------
+// game.step + tree reuse (src/parallel_trainer.py:190-198, src/game.py:156-187)
+__global__ __launch_bounds__(64) void k_advance(EngineView E, const int16_t* actions) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    const int a = actions[g];
+    if (a < 0) return;
+    const size_t pool = (size_t)g * E.cap;
+    const uint32_t r = E.root[g];
+    uint32_t newroot = NODE_NONE;
+    if (r != NODE_NONE) {
+        const int k = (E.IN[pool + r] >> 8) & 0xFF;
+        const uint32_t fc = E.FC[pool + r];
+        const bool hit = (lane < k) && ((int)(E.IN[pool + fc + lane] & 0xFF) == a);
+        const unsigned long long m = __ballot(hit);
+        if (m) newroot = fc + (__ffsll((long long)m) - 1);
+    }
+    if (lane == 0) {
+        E.root[g] = newroot;
+        E.root_mode[g] = 0;
+        if (newroot == NODE_NONE) E.used[g] = 0;
+        uint64_t w = E.white[g], b = E.black[g];
+        const int t = E.turn[g];
+        int win = E.winner[g];
+        const int sq = a / 3, d = a - 3 * sq;
+        const int to = sq + ((d == 0) ? 8 : ((d == 1) ? 7 : 9));
+        const int rf = (t > 0) ? sq : 63 - sq, rt = (t > 0) ? to : 63 - to;
+        const uint64_t fb = 1ull << (rf & 63), tb = 1ull << (rt & 63);
+        if (t > 0) { w = (w & ~fb) | tb; b &= ~tb; if ((rt >> 3) == 7) win = 1; if (win == 0 && b == 0) win = 1; }
+        else       { b = (b & ~fb) | tb; w &= ~tb; if ((rt >> 3) == 0) win = -1; if (win == 0 && w == 0) win = -1; }
+        E.white[g] = w; E.black[g] = b; E.turn[g] = (int8_t)(-t); E.winner[g] = (int8_t)win;
+        E.ply[g] = E.ply[g] + 1;
+    }
+}
+
+__global__ void k_set_positions(EngineView E, int n, const int32_t* slots, const uint64_t* w,
+                                const uint64_t* b, const int8_t* t, const int8_t* win) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int g = slots[i];
+    E.white[g] = w[i]; E.black[g] = b[i]; E.turn[g] = t[i]; E.winner[g] = win[i];
+    E.root[g] = NODE_NONE; E.used[g] = 0; E.root_mode[g] = 0; E.ply[g] = 0; E.leaf_need[g] = 0;
+}
+
+__global__ void k_set_root(EngineView E, int g, int64_t node) {
+    if (node < 0) { E.root[g] = NODE_NONE; E.used[g] = 0; }
+    else E.root[g] = (uint32_t)node;
+    E.root_mode[g] = 0;
+}
+
+__global__ __launch_bounds__(64) void k_node_children(EngineView E, int g, int64_t node_in,
+                                                      NodeQuery* out) {
+    const int lane = threadIdx.x;
+    const size_t pool = (size_t)g * E.cap;
+    const uint32_t r = E.root[g];
+    const uint32_t node = (node_in < 0) ? r : (uint32_t)node_in;
+    if (node == NODE_NONE) { if (lane == 0) { out->k = -1; out->node_index = -1; } return; }
+    const uint32_t inf = E.IN[pool + node];
+    const int k = (inf >> 8) & 0xFF;
+    const uint32_t fc = E.FC[pool + node];
+    const bool root64 = (node == r) && E.root_mode[g];
+    const bool uni = (inf >> 16) & FLAG_UNIFORM64;
+    if (lane == 0) {
+        out->k = k; out->node_visits = E.N[pool + node]; out->node_value_sum = E.W[pool + node];
+        out->node_index = node;
+    }
+    if (lane < k) {
+        out->actions[lane] = (uint8_t)(E.IN[pool + fc + lane] & 0xFF);
+        out->visits[lane] = E.N[pool + fc + lane];
+        out->value_sum[lane] = E.W[pool + fc + lane];
+        out->prior64[lane] = root64 ? E.root_p64[(size_t)g * 48 + lane]
+                                    : (uni ? 1.0 / (double)k : (double)E.P[pool + fc + lane]);
+        out->prior_is64[lane] = (root64 || uni) ? 1 : 0;
+        out->child_index[lane] = (int64_t)(fc + lane);
+    }
+}
+
+}  // namespace az
+
+using namespace az;
+
+// ---------------------------------------------------------------------------
+static int engine_alloc(az_engine* e) {
+    EngineView& V = e->v;
+    const size_t B = (size_t)V.B, cap = (size_t)V.cap;
+#define AZ_ALLOC(ptr, count)                                                          \
+    do {                                                                              \
+        void* _p = nullptr;                                                           \
+        AZ_HIP(hipMalloc(&_p, (count) * sizeof(*(ptr))));                             \
+        AZ_HIP(hipMemset(_p, 0, (count) * sizeof(*(ptr))));                           \
+        (ptr) = (decltype(ptr))_p;                                                    \
+        e->allocs.push_back(_p);                                                      \
+    } while (0)
+    AZ_ALLOC(V.white, B); AZ_ALLOC(V.black, B); AZ_ALLOC(V.turn, B); AZ_ALLOC(V.winner, B);
+    AZ_ALLOC(V.active, B); AZ_ALLOC(V.ply, B); AZ_ALLOC(V.root, B); AZ_ALLOC(V.used, B);
+    AZ_ALLOC(V.root_mode, B); AZ_ALLOC(V.root_p64, B * 48);
+    AZ_ALLOC(V.leaf_node, B); AZ_ALLOC(V.leaf_mine, B); AZ_ALLOC(V.leaf_theirs, B);
+    AZ_ALLOC(V.leaf_turn, B); AZ_ALLOC(V.leaf_need, B); AZ_ALLOC(V.leaf_tv, B);
+    AZ_ALLOC(V.path_len, B); AZ_ALLOC(V.path, B * MAX_DEPTH);
+    AZ_ALLOC(V.N, B * cap); AZ_ALLOC(V.W, B * cap); AZ_ALLOC(V.P, B * cap);
+    AZ_ALLOC(V.FC, B * cap); AZ_ALLOC(V.IN, B * cap);
+    AZ_ALLOC(V.err, 1); AZ_ALLOC(V.stat_depth, 1); AZ_ALLOC(V.stat_descents, 1);
+    AZ_ALLOC(e->stage_slots, B); AZ_ALLOC(e->stage_w, B); AZ_ALLOC(e->stage_b, B);
+    AZ_ALLOC(e->stage_t, B); AZ_ALLOC(e->stage_win, B); AZ_ALLOC(e->stage_act, B);
+    AZ_ALLOC(e->stage_temps, B); AZ_ALLOC(e->query_dev, 1);
+#undef AZ_ALLOC
+    AZ_HIP(hipHostMalloc((void**)&e->query_host, sizeof(NodeQuery), hipHostMallocDefault));
+    AZ_HIP(hipMemset(V.active, 1, B));
+    AZ_HIP(hipMemset(V.root, 0xFF, B * sizeof(uint32_t)));
+    return AZ_OK;
+}
+
+extern "C" int az_engine_create(az_engine** out, const az_engine_config* cfg) {
+    AZ_CHECK_ARG(out && cfg, "az_engine_create: null argument");
+    AZ_CHECK_ARG(cfg->n_games > 0 && cfg->n_games <= (1 << 20), "az_engine_create: n_games = %d out of range",
+                 cfg->n_games);
+    if (cfg->device >= 0) AZ_HIP(hipSetDevice(cfg->device));
+    az_engine* e = new az_engine();
+    AZ_HIP(hipGetDevice(&e->device));
+    EngineView& V = e->v;
+    V.B = cfg->n_games;
+    V.c_puct = cfg->c_puct;
+    V.alpha = cfg->dirichlet_alpha;
+    V.eps = cfg->dirichlet_epsilon;
+    V.temp_thr = cfg->temperature_threshold;
+    V.seed = cfg->seed;
+    int64_t cap = cfg->pool_nodes_per_game;
+    if (cap <= 0) cap = 1 << 20;
+    AZ_CHECK_ARG(cap >= 64 && cap < (1ll << 31), "az_engine_create: pool_nodes_per_game out of range");
+    V.cap = (uint32_t)cap;
+    const int rc = engine_alloc(e);
+    if (rc != AZ_OK) { az_engine_destroy(e); return rc; }
+    *out = e;
+    return AZ_OK;
+}
+
+extern "C" int az_engine_destroy(az_engine* e) {
+    if (!e) return AZ_OK;
+    for (void* p : e->allocs) (void)hipFree(p);
+    if (e->query_host) (void)hipHostFree(e->query_host);
+    delete e;
+    return AZ_OK;
+}
+
+static int check_err(az_engine* e, hipStream_t s) {
+    int32_t flag = 0;
+    AZ_HIP(hipMemcpyAsync(&flag, e->v.err, sizeof flag, hipMemcpyDeviceToHost, s));
+    AZ_HIP(hipStreamSynchronize(s));
+    if (flag & ERR_POOL) AZ_FAIL(AZ_ERR_CAPACITY, "node pool exhausted (pool_nodes_per_game = %u)", e->v.cap);
+    if (flag & ERR_DEPTH) AZ_FAIL(AZ_ERR_CAPACITY, "selection path deeper than %d", MAX_DEPTH);
+    return AZ_OK;
+}
+
+extern "C" int az_engine_set_positions(az_engine* e, int32_t n, const int32_t* slots_host,
+                                       const uint64_t* white_host, const uint64_t* black_host,
+                                       const int8_t* turn_host, const int8_t* winner_host,
+                                       void* stream) {
+    AZ_CHECK_ARG(e && n >= 0 && n <= e->v.B, "az_engine_set_positions: bad n");
+    if (n == 0) return AZ_OK;
+    AZ_CHECK_ARG(slots_host && white_host && black_host && turn_host, "az_engine_set_positions: null pointer");
+    for (int i = 0; i < n; ++i)
+        AZ_CHECK_ARG(slots_host[i] >= 0 && slots_host[i] < e->v.B, "az_engine_set_positions: slot %d out of range",
+                     slots_host[i]);
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<int8_t> zero;
+    if (!winner_host) { zero.assign(n, 0); winner_host = zero.data(); }
+    AZ_HIP(hipMemcpyAsync(e->stage_slots, slots_host, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    AZ_HIP(hipMemcpyAsync(e->stage_w, white_host, n * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    AZ_HIP(hipMemcpyAsync(e->stage_b, black_host, n * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    AZ_HIP(hipMemcpyAsync(e->stage_t, turn_host, n, hipMemcpyHostToDevice, s));
+    AZ_HIP(hipMemcpyAsync(e->stage_win, winner_host, n, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_set_positions, dim3((n + 255) / 256), dim3(256), 0, s, e->v, n, e->stage_slots,
+                       e->stage_w, e->stage_b, e->stage_t, e->stage_win);
+    AZ_HIP(hipGetLastError());
+    AZ_HIP(hipStreamSynchronize(s));  // the staging buffers and host arrays are free again
+    return AZ_OK;
+}
+
+extern "C" int az_engine_get_positions(az_engine* e, uint64_t* white_host, uint64_t* black_host,
+                                       int8_t* turn_host, int8_t* winner_host, void* stream) {
+    AZ_CHECK_ARG(e, "az_engine_get_positions: null engine");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t B = e->v.B;
+    if (white_host) AZ_HIP(hipMemcpyAsync(white_host, e->v.white, B * 8, hipMemcpyDeviceToHost, s));
+    if (black_host) AZ_HIP(hipMemcpyAsync(black_host, e->v.black, B * 8, hipMemcpyDeviceToHost, s));
+    if (turn_host) AZ_HIP(hipMemcpyAsync(turn_host, e->v.turn, B, hipMemcpyDeviceToHost, s));
+    if (winner_host) AZ_HIP(hipMemcpyAsync(winner_host, e->v.winner, B, hipMemcpyDeviceToHost, s));
+    AZ_HIP(hipStreamSynchronize(s));
+    return AZ_OK;
+}
+
+extern "C" int az_engine_set_active(az_engine* e, const uint8_t* active_host, void* stream) {
+    AZ_CHECK_ARG(e && active_host, "az_engine_set_active: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    AZ_HIP(hipMemcpyAsync(e->v.active, active_host, e->v.B, hipMemcpyHostToDevice, s));
+    AZ_HIP(hipStreamSynchronize(s));
+    return AZ_OK;
+}
+
+extern "C" int az_engine_roots_prepare(az_engine* e, float* planes_dev, uint8_t* need_eval_dev,
+                                       void* stream) {
+    AZ_CHECK_ARG(e, "az_engine_roots_prepare: null engine");
+    AZ_CHECK_ARG(((uintptr_t)planes_dev & 15) == 0, "az_engine_roots_prepare: planes must be 16-byte aligned");
+    hipLaunchKernelGGL(k_roots_prepare, dim3(e->v.B), dim3(64), 0, (hipStream_t)stream, e->v, planes_dev,
+                       need_eval_dev);
+    AZ_HIP(hipGetLastError());
+    e->phase = PHASE_ROOTS;
+    return AZ_OK;
+}
+
+extern "C" int az_engine_roots_expand(az_engine* e, const float* probs_dev, void* stream) {
+    AZ_CHECK_ARG(e && probs_dev, "az_engine_roots_expand: null argument");
+    if (e->phase != PHASE_ROOTS) AZ_FAIL(AZ_ERR_STATE, "az_engine_roots_expand without az_engine_roots_prepare");
+    hipLaunchKernelGGL(k_expand_backup, dim3(e->v.B), dim3(64), 0, (hipStream_t)stream, e->v, probs_dev,
+                       (const float*)nullptr, 0);
+    AZ_HIP(hipGetLastError());
+    e->phase = PHASE_IDLE;
+    return AZ_OK;
+}
+
+extern "C" int az_engine_add_noise(az_engine* e, const double* noise_dev, void* stream) {
+    AZ_CHECK_ARG(e, "az_engine_add_noise: null engine");
+    hipLaunchKernelGGL(k_add_noise, dim3(e->v.B), dim3(64), 0, (hipStream_t)stream, e->v, noise_dev,
+                       ++e->noise_calls);
+    AZ_HIP(hipGetLastError());
+    return AZ_OK;
+}
+
+extern "C" int az_engine_select(az_engine* e, float* planes_dev, uint8_t* need_eval_dev, void* stream) {
+    AZ_CHECK_ARG(e, "az_engine_select: null engine");
+    AZ_CHECK_ARG(((uintptr_t)planes_dev & 15) == 0, "az_engine_select: planes must be 16-byte aligned");
+    hipLaunchKernelGGL(k_select, dim3(e->v.B), dim3(64), 0, (hipStream_t)stream, e->v, planes_dev,
+                       need_eval_dev);
+    AZ_HIP(hipGetLastError());
+    e->phase = PHASE_SELECTED;
+    return AZ_OK;
+}
+
+extern "C" int az_engine_expand_backup(az_engine* e, const float* probs_dev, const float* values_dev,
+                                       void* stream) {
+    AZ_CHECK_ARG(e && probs_dev && values_dev, "az_engine_expand_backup: null argument");
+    if (e->phase != PHASE_SELECTED) AZ_FAIL(AZ_ERR_STATE, "az_engine_expand_backup without az_engine_select");
+    hipLaunchKernelGGL(k_expand_backup, dim3(e->v.B), dim3(64), 0, (hipStream_t)stream, e->v, probs_dev,
+                       values_dev, 1);
+    AZ_HIP(hipGetLastError());
+    e->phase = PHASE_IDLE;
+    return AZ_OK;
+}
+
+extern "C" int az_engine_node_children(az_engine* e, int32_t g, int64_t node, int32_t* k_host,
+                                       uint8_t* actions_host, uint32_t* visits_host,
+                                       float* value_sum_host, double* prior64_host,
+                                       uint8_t* prior_is64_host, int64_t* child_index_host,
+                                       uint32_t* node_visits_host, float* node_value_sum_host,
+                                       int64_t* node_index_host, void* stream) {
+    AZ_CHECK_ARG(e && g >= 0 && g < e->v.B, "az_engine_node_children: game %d out of range", g);
+    AZ_CHECK_ARG(node < (int64_t)e->v.cap, "az_engine_node_children: node out of range");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_node_children, dim3(1), dim3(64), 0, s, e->v, g, node, e->query_dev);
+    AZ_HIP(hipGetLastError());
+    AZ_HIP(hipMemcpyAsync(e->query_host, e->query_dev, sizeof(NodeQuery), hipMemcpyDeviceToHost, s));
+    const int rc = check_err(e, s);  // synchronises
+    if (rc != AZ_OK) return rc;
+    const NodeQuery& q = *e->query_host;
+    const int k = q.k < 0 ? 0 : q.k;
+    if (k_host) *k_host = q.k;
+    if (node_visits_host) *node_visits_host = q.node_visits;
+    if (node_value_sum_host) *node_value_sum_host = q.node_value_sum;
+    if (node_index_host) *node_index_host = q.node_index;
+    for (int i = 0; i < k; ++i) {
+        if (actions_host) actions_host[i] = q.actions[i];
+        if (visits_host) visits_host[i] = q.visits[i];
+        if (value_sum_host) value_sum_host[i] = q.value_sum[i];
+        if (prior64_host) prior64_host[i] = q.prior64[i];
+        if (prior_is64_host) prior_is64_host[i] = q.prior_is64[i];
+        if (child_index_host) child_index_host[i] = q.child_index[i];
+    }
+    return AZ_OK;
+}
+
+extern "C" int az_engine_action_probs(az_engine* e, const float* temps_host, float* probs_dev,
+                                      void* stream) {
+    AZ_CHECK_ARG(e && probs_dev, "az_engine_action_probs: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const float* temps_dev = nullptr;
+    if (temps_host) {
+        for (int i = 0; i < e->v.B; ++i)
+            AZ_CHECK_ARG(temps_host[i] == 0.0f || temps_host[i] == 1.0f,
+                         "az_engine_action_probs: temperature %g (only 0 and 1 are supported)", temps_host[i]);
+        AZ_HIP(hipMemcpyAsync(e->stage_temps, temps_host, e->v.B * sizeof(float), hipMemcpyHostToDevice, s));
+        temps_dev = e->stage_temps;
+    }
+    hipLaunchKernelGGL(k_action_probs, dim3(e->v.B), dim3(64), 0, s, e->v, temps_dev, probs_dev);
+    AZ_HIP(hipGetLastError());
+    if (temps_host) AZ_HIP(hipStreamSynchronize(s));
+    return AZ_OK;
+}
+
+extern "C" int az_engine_advance(az_engine* e, const int16_t* actions_host, void* stream) {
+    AZ_CHECK_ARG(e && actions_host, "az_engine_advance: null argument");
+    for (int i = 0; i < e->v.B; ++i)
+        AZ_CHECK_ARG(actions_host[i] < 192, "az_engine_advance: action %d out of range", actions_host[i]);
+    hipStream_t s = (hipStream_t)stream;
+    AZ_HIP(hipMemcpyAsync(e->stage_act, actions_host, e->v.B * sizeof(int16_t), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_advance, dim3(e->v.B), dim3(64), 0, s, e->v, e->stage_act);
+    AZ_HIP(hipGetLastError());
+    AZ_HIP(hipStreamSynchronize(s));
+    return AZ_OK;
+}
+
+extern "C" int az_engine_set_root(az_engine* e, int32_t g, int64_t node, void* stream) {
+    AZ_CHECK_ARG(e && g >= 0 && g < e->v.B, "az_engine_set_root: game %d out of range", g);
+    AZ_CHECK_ARG(node < (int64_t)e->v.cap, "az_engine_set_root: node out of range");
+    hipLaunchKernelGGL(k_set_root, dim3(1), dim3(1), 0, (hipStream_t)stream, e->v, g, node);
+    AZ_HIP(hipGetLastError());
+    return AZ_OK;
+}
+
+extern "C" int az_engine_pool_usage(az_engine* e, uint32_t* used_host, void* stream) {
+    AZ_CHECK_ARG(e, "az_engine_pool_usage: null engine");
+    hipStream_t s = (hipStream_t)stream;
+    if (used_host) AZ_HIP(hipMemcpyAsync(used_host, e->v.used, e->v.B * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    return check_err(e, s);
+}
+
+extern "C" int az_engine_stats(az_engine* e, uint64_t* depth_sum_host, uint64_t* descents_host,
+                               void* stream) {
+    AZ_CHECK_ARG(e, "az_engine_stats: null engine");
+    hipStream_t s = (hipStream_t)stream;
+    if (depth_sum_host) AZ_HIP(hipMemcpyAsync(depth_sum_host, e->v.stat_depth, 8, hipMemcpyDeviceToHost, s));
+    if (descents_host) AZ_HIP(hipMemcpyAsync(descents_host, e->v.stat_descents, 8, hipMemcpyDeviceToHost, s));
+    AZ_HIP(hipStreamSynchronize(s));
+    return AZ_OK;
+}

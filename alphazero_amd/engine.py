@@ -1,0 +1,187 @@
+"""Python handle on the device search engine (az_engine_* in include/azamd.h).
+
+PyTorch is used for device memory and the current HIP stream only; every
+computation happens in libazamd.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+
+
+def _dev_ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _host_ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Engine:
+    """B games, one tree each, resident on one GPU."""
+
+    def __init__(self, n_games, c_puct=1.5, dirichlet_alpha=0.35, dirichlet_epsilon=0.25,
+                 temperature_threshold=16, pool_nodes_per_game=0, seed=0, device=None):
+        if not torch.cuda.is_available():
+            raise _lib.AzError("alphazero_amd.Engine needs a GPU (no CPU fallback exists)")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.n = int(n_games)
+        cfg = _lib.EngineConfig(self.n, float(c_puct), float(dirichlet_alpha),
+                                float(dirichlet_epsilon), int(temperature_threshold),
+                                int(pool_nodes_per_game), int(seed), self.device.index)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(_lib.lib().az_engine_create(C.byref(h), C.byref(cfg)))
+        self.h = h
+        self.planes = torch.zeros((self.n, 3, 8, 8), dtype=torch.float32, device=self.device)
+        self.need = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
+        self.probs = torch.zeros((self.n, 192), dtype=torch.float32, device=self.device)
+        self.values = torch.zeros(self.n, dtype=torch.float32, device=self.device)
+        self.net = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            _lib.lib().az_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------ positions
+    def set_positions(self, slots, white, black, turn, winner=None):
+        slots = np.ascontiguousarray(slots, np.int32)
+        white = np.ascontiguousarray(white, np.uint64)
+        black = np.ascontiguousarray(black, np.uint64)
+        turn = np.ascontiguousarray(turn, np.int8)
+        winner = None if winner is None else np.ascontiguousarray(winner, np.int8)
+        with torch.cuda.device(self.device):
+            check(_lib.lib().az_engine_set_positions(
+                self.h, len(slots), _host_ptr(slots), _host_ptr(white), _host_ptr(black),
+                _host_ptr(turn), _host_ptr(winner), _stream()))
+
+    def reset_all(self):
+        n = self.n
+        self.set_positions(np.arange(n), np.full(n, 0xFFFF, np.uint64),
+                           np.full(n, 0xFFFF << 48, np.uint64), np.ones(n, np.int8))
+
+    def get_positions(self):
+        white = np.zeros(self.n, np.uint64)
+        black = np.zeros(self.n, np.uint64)
+        turn = np.zeros(self.n, np.int8)
+        winner = np.zeros(self.n, np.int8)
+        with torch.cuda.device(self.device):
+            check(_lib.lib().az_engine_get_positions(self.h, _host_ptr(white), _host_ptr(black),
+                                                     _host_ptr(turn), _host_ptr(winner), _stream()))
+        return white, black, turn, winner
+
+    def set_active(self, active):
+        a = np.ascontiguousarray(active, np.uint8)
+        assert a.shape == (self.n,)
+        with torch.cuda.device(self.device):
+            check(_lib.lib().az_engine_set_active(self.h, _host_ptr(a), _stream()))
+
+    # ------------------------------------------------------------ search steps
+    def roots_prepare(self):
+        check(_lib.lib().az_engine_roots_prepare(self.h, _dev_ptr(self.planes), _dev_ptr(self.need), _stream()))
+
+    def roots_expand(self, probs):
+        assert probs.is_cuda and probs.dtype == torch.float32 and probs.shape == (self.n, 192) and probs.is_contiguous()
+        check(_lib.lib().az_engine_roots_expand(self.h, _dev_ptr(probs), _stream()))
+
+    def add_noise(self, noise=None):
+        """noise: [n,48] float64 Dirichlet draws (host array or cuda tensor) or None
+        to draw on the device."""
+        if noise is not None and not torch.is_tensor(noise):
+            noise = torch.from_numpy(np.ascontiguousarray(noise, np.float64)).to(self.device)
+        if noise is not None:
+            assert noise.dtype == torch.float64 and noise.shape == (self.n, 48) and noise.is_contiguous()
+        check(_lib.lib().az_engine_add_noise(self.h, _dev_ptr(noise), _stream()))
+
+    def select(self):
+        check(_lib.lib().az_engine_select(self.h, _dev_ptr(self.planes), _dev_ptr(self.need), _stream()))
+
+    def expand_backup(self, probs, values):
+        assert probs.is_cuda and probs.dtype == torch.float32 and probs.shape == (self.n, 192) and probs.is_contiguous()
+        assert values.is_cuda and values.dtype == torch.float32 and values.shape == (self.n,) and values.is_contiguous()
+        check(_lib.lib().az_engine_expand_backup(self.h, _dev_ptr(probs), _dev_ptr(values), _stream()))
+
+    # ------------------------------------------------------------ queries
+    def node_children(self, g, node=-1):
+        k = C.c_int32()
+        act = np.zeros(48, np.uint8)
+        N = np.zeros(48, np.uint32)
+        W = np.zeros(48, np.float32)
+        P = np.zeros(48, np.float64)
+        is64 = np.zeros(48, np.uint8)
+        idx = np.zeros(48, np.int64)
+        nN = C.c_uint32()
+        nW = C.c_float()
+        nidx = C.c_int64()
+        with torch.cuda.device(self.device):
+            check(_lib.lib().az_engine_node_children(
+                self.h, int(g), int(node), C.byref(k), _host_ptr(act), _host_ptr(N), _host_ptr(W),
+                _host_ptr(P), _host_ptr(is64), _host_ptr(idx), C.byref(nN), C.byref(nW),
+                C.byref(nidx), _stream()))
+        if k.value < 0:
+            return None
+        kk = k.value
+        return dict(actions=act[:kk].copy(), N=N[:kk].copy(), W=W[:kk].copy(), P=P[:kk].copy(),
+                    p_is64=is64[:kk].copy(), index=idx[:kk].copy(), root_N=int(nN.value),
+                    root_W=float(nW.value), node=int(nidx.value))
+
+    def root_children(self, g):
+        return self.node_children(g, -1)
+
+    def action_probs_all(self, temps=None, out=None):
+        out = self.probs if out is None else out
+        t = None if temps is None else np.ascontiguousarray(temps, np.float32)
+        check(_lib.lib().az_engine_action_probs(self.h, _host_ptr(t), _dev_ptr(out), _stream()))
+        return out
+
+    def advance_all(self, actions):
+        a = np.ascontiguousarray(actions, np.int16)
+        assert a.shape == (self.n,)
+        with torch.cuda.device(self.device):
+            check(_lib.lib().az_engine_advance(self.h, _host_ptr(a), _stream()))
+
+    def set_root(self, g, node):
+        check(_lib.lib().az_engine_set_root(self.h, int(g), int(node), _stream()))
+
+    def pool_usage(self):
+        used = np.zeros(self.n, np.uint32)
+        with torch.cuda.device(self.device):
+            check(_lib.lib().az_engine_pool_usage(self.h, _host_ptr(used), _stream()))
+        return used
+
+    def mean_depth(self):
+        d, n = C.c_uint64(), C.c_uint64()
+        check(_lib.lib().az_engine_stats(self.h, C.byref(d), C.byref(n), _stream()))
+        return d.value / max(1, n.value)
+
+    # ------------------------------------------------------------ one search_batch
+    def search_with(self, evaluate, num_simulations, add_noise=False, noise=None):
+        """MCTS.search_batch (src/mcts.py:94-189) with an arbitrary evaluator between
+        the device steps.  evaluate(planes_cuda[n,3,8,8], need_cuda[n]) ->
+        (probs_cuda[n,192] f32, values_cuda[n] f32)."""
+        self.roots_prepare()
+        if bool(self.need.any().item()):
+            probs, _ = evaluate(self.planes, self.need)
+            self.roots_expand(probs)
+        else:
+            self.roots_expand(self.probs)
+        if add_noise or noise is not None:
+            self.add_noise(noise)
+        for _ in range(num_simulations):
+            self.select()
+            probs, values = evaluate(self.planes, self.need)
+            self.expand_backup(probs, values)

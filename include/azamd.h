@@ -1,0 +1,139 @@
+/*
+ * azamd.h — C ABI of libazamd.so, the gfx950 (MI355X) self-play library.
+ *
+ * The reference (pierre-roth/AlphaZero) is pure Python and has no FFI of its
+ * own; each entry point below names the reference function(s) it replaces as
+ * file:line under the reference checkout.  All pointers named *_dev are device
+ * (HBM) pointers owned by the caller; *_host are host pointers.  `stream` is a
+ * hipStream_t passed as void* (NULL = the default stream).  Every function
+ * returns 0 on success or a negative AZ_ERR_* code; az_last_error() then
+ * returns a thread-local message.  Nothing throws across this boundary.
+ *
+ * Board convention: bit (row*8+col) of a 64-bit word; row 0 is White's home
+ * row; turn +1 = WHITE, -1 = BLACK (src/game.py:28-31,
+ * tests/test_compatibility.py:8-17).  "Canonical" means seen by the side to
+ * move: for Black the board is rotated by 180 degrees (src/game.py:299-302),
+ * which on bitboards is a 64-bit bit reversal with the colours swapped.
+ */
+#ifndef AZAMD_H
+#define AZAMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AZ_OK 0
+#define AZ_ERR_ARG (-1)      /* bad argument (null pointer, size out of range) */
+#define AZ_ERR_HIP (-2)      /* a HIP runtime call failed */
+#define AZ_ERR_STATE (-3)    /* call sequence violated */
+#define AZ_ERR_CAPACITY (-4) /* node pool / history exhausted */
+
+const char* az_last_error(void);
+int az_version(void);
+
+/* ------------------------------------------------------------------------
+ * Stateless batch move generation / terminal detection / encoding.
+ * Replaces, per position: BreakthroughGame.get_legal_moves (src/game.py:109-150),
+ * get_legal_action_mask (:309-315), get_encoded_state (:280-307) and the
+ * board-derivable part of _check_winner / is_terminal (:175-194).
+ *
+ *   white_dev, black_dev [n] u64, turn_dev [n] i8 (+1 / -1)        inputs
+ *   legal3_dev  [n][3] u64  canonical source squares that may move forward /
+ *                           diagonal-left / diagonal-right (action = sq*3+dir)
+ *   mask192_dev [n][192] u8 the reference's boolean mask, one byte per action
+ *   planes_dev  [n][3][8][8] f32 the reference's encoded state
+ *   status_dev  [n] i8  0 live; +1 / -1 a side has won on the board (a piece
+ *                       on its goal row, or the other side extinct); 2 the
+ *                       side to move has no legal move
+ * Any output pointer may be NULL.  n may be 0.
+ */
+int az_movegen_encode(int64_t n, const uint64_t* white_dev, const uint64_t* black_dev,
+                      const int8_t* turn_dev, uint64_t* legal3_dev, uint8_t* mask192_dev,
+                      float* planes_dev, int8_t* status_dev, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Search engine: B independent games, one tree each, nodes in an SoA pool in
+ * HBM, one wavefront per game.  Replaces MCTS.search_batch and its helpers
+ * (src/mcts.py:94-189, 260-342) plus the per-move bookkeeping of
+ * ParallelTrainer.execute_parallel_episodes (src/parallel_trainer.py:176-198).
+ */
+typedef struct az_engine az_engine;
+
+typedef struct {
+    int32_t n_games;              /* B */
+    double  c_puct;               /* src/config.py:35 (a Python float) */
+    double  dirichlet_alpha;      /* src/config.py:40 */
+    double  dirichlet_epsilon;    /* src/config.py:41 */
+    int32_t temperature_threshold;/* src/config.py:42 */
+    int64_t pool_nodes_per_game;  /* 0 = default */
+    uint64_t seed;                /* device RNG (noise, move sampling) */
+    int32_t device;               /* HIP device ordinal, -1 = current */
+} az_engine_config;
+
+int az_engine_create(az_engine** out, const az_engine_config* cfg);
+int az_engine_destroy(az_engine* e);
+
+/* Set game g's position and drop its tree (root = None).  Host arrays of
+ * length n; slots_host[i] is the game index.  winner_host may be NULL (= 0). */
+int az_engine_set_positions(az_engine* e, int32_t n, const int32_t* slots_host,
+                            const uint64_t* white_host, const uint64_t* black_host,
+                            const int8_t* turn_host, const int8_t* winner_host, void* stream);
+int az_engine_get_positions(az_engine* e, uint64_t* white_host, uint64_t* black_host,
+                            int8_t* turn_host, int8_t* winner_host, void* stream);
+/* Games with active == 0 are skipped by every step below (the shrinking
+ * active list of src/parallel_trainer.py:158-217). */
+int az_engine_set_active(az_engine* e, const uint8_t* active_host, void* stream);
+
+/* One search_batch call, step by step (so that any evaluator can sit between
+ * the steps).  planes_dev [B][3][8][8] f32, need_eval_dev [B] u8,
+ * probs_dev [B][192] f32 (softmaxed policy), values_dev [B] f32.
+ *   roots_prepare  src/mcts.py:117-133   create missing roots, emit those to expand
+ *   roots_expand   src/mcts.py:135-138   expand them; the value is not backed up
+ *   add_noise      src/mcts.py:141-144, 314-326; noise_dev [B][48] f64 Dirichlet
+ *                  draws in child insertion order, or NULL to draw on the device
+ *   select         src/mcts.py:153-171   one PUCT descent per game
+ *   expand_backup  src/mcts.py:174-187   expand + back up evaluated leaves,
+ *                                        back up terminal leaves
+ */
+int az_engine_roots_prepare(az_engine* e, float* planes_dev, uint8_t* need_eval_dev, void* stream);
+int az_engine_roots_expand(az_engine* e, const float* probs_dev, void* stream);
+int az_engine_add_noise(az_engine* e, const double* noise_dev, void* stream);
+int az_engine_select(az_engine* e, float* planes_dev, uint8_t* need_eval_dev, void* stream);
+int az_engine_expand_backup(az_engine* e, const float* probs_dev, const float* values_dev,
+                            void* stream);
+
+/* Children of a node in insertion order (Node.children, src/mcts.py:21-40).
+ * node = -1 means game g's root.  Host outputs, each with room for 48 entries;
+ * prior64 holds the prior widened to double, prior_is64 says whether the
+ * reference would hold it as float64.  child_index receives pool indices that
+ * can be passed back as `node`.  Synchronises the stream. */
+int az_engine_node_children(az_engine* e, int32_t g, int64_t node, int32_t* k_host,
+                            uint8_t* actions_host, uint32_t* visits_host, float* value_sum_host,
+                            double* prior64_host, uint8_t* prior_is64_host,
+                            int64_t* child_index_host, uint32_t* node_visits_host,
+                            float* node_value_sum_host, int64_t* node_index_host, void* stream);
+
+/* MCTS.get_action_probs (src/mcts.py:191-225) for every active game, with the
+ * temperature schedule of src/parallel_trainer.py:164 when temps_host is NULL
+ * (1.0 while the game's ply count < temperature_threshold, else 0), or the
+ * given per-game temperatures (each must be 0 or 1).  probs_dev [B][192] f32. */
+int az_engine_action_probs(az_engine* e, const float* temps_host, float* probs_dev, void* stream);
+
+/* src/parallel_trainer.py:190-198: play action actions_host[g] (< 0: leave the
+ * game alone) and re-root the tree at that child (None if absent). */
+int az_engine_advance(az_engine* e, const int16_t* actions_host, void* stream);
+/* Re-root game g at an arbitrary pool node without touching the position
+ * (callers that pass Node handles back as roots). node = -1 drops the tree. */
+int az_engine_set_root(az_engine* e, int32_t g, int64_t node, void* stream);
+
+/* Diagnostics: nodes in use per game, sticky capacity-error flag. */
+int az_engine_pool_usage(az_engine* e, uint32_t* used_host, void* stream);
+/* Sum of selection path lengths (nodes below the root) and number of descents
+ * since creation: mean depth = depth_sum / descents. */
+int az_engine_stats(az_engine* e, uint64_t* depth_sum_host, uint64_t* descents_host, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,109 @@
+"""GPU parity, tree tier: visit counts, value sums and priors of the device
+search must be bit-identical to the reference (golden fixtures) and to the CPU
+oracle, given the same network outputs."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from fake_net import TableEvaluator
+from test_oracle_golden import _check_children
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tree_tier(golden_dir):
+    return np.load(os.path.join(golden_dir, "tree_tier.npz"))
+
+
+@pytest.mark.parametrize("S", [1, 2, 50, 100, 800])
+def test_fresh_search_matches_reference(tree_tier, S):
+    from gpu_backend import EngineBackend
+    d = tree_tier
+    nG = len(d["white"])
+    m = EngineBackend(nG, pool_nodes_per_game=1 << 16)
+    for g in range(nG):
+        m.set_game(g, orc.make_pos(d["white"][g], d["black"][g], d["turn"][g]))
+    m.search(TableEvaluator(), S)
+    for g in range(nG):
+        _check_children(m.root_children(g), d, f"fresh{S}", g)
+
+
+@pytest.mark.parametrize("tag", ["reuse", "noisy"])
+def test_reuse_sequence_matches_reference(tree_tier, tag):
+    from gpu_backend import EngineBackend
+    d = tree_tier
+    games = d[f"{tag}_games"]
+    S = int(d[f"{tag}_sims"])
+    actions = d[f"{tag}_played"]
+    nG = len(games)
+    ev = TableEvaluator()
+    m = EngineBackend(nG, pool_nodes_per_game=1 << 16)
+    for j, g in enumerate(games):
+        m.set_game(j, orc.make_pos(d["white"][g], d["black"][g], d["turn"][g]))
+    alive = np.ones(nG, bool)
+    for ply in range(actions.shape[0]):
+        if not alive.any():
+            break
+        m.set_active(alive)
+        noise = d[f"{tag}_noise"][ply] if tag == "noisy" else None
+        m.search(ev, S, noise=noise)
+        for j in range(nG):
+            if not alive[j]:
+                continue
+            _check_children(m.root_children(j), d, tag, (ply, j))
+            m.advance(j, int(actions[ply, j]))
+            if orc.is_terminal(m.get_game(j)):
+                alive[j] = False
+
+
+def test_selfplay_stream_matches_reference(golden_dir):
+    from gpu_backend import EngineBackend
+    from selfplay_replay import replay_selfplay
+    d = np.load(os.path.join(golden_dir, "selfplay_tier.npz"))
+    nG, S = int(d["n_games"]), int(d["sims"])
+    states, policies, wls = replay_selfplay(EngineBackend(nG, pool_nodes_per_game=1 << 16), nG, S,
+                                            d["dirichlet"], d["choices"], TableEvaluator())
+    n = int(d["n_examples"])
+    ref_states = np.unpackbits(d["states"])[: n * 192].reshape(n, 3, 8, 8).astype(np.float32)
+    assert np.array_equal(np.array(states), ref_states)
+    assert np.array_equal(np.array(policies).view(np.uint32), d["policies"].view(np.uint32))
+    assert np.array_equal(np.array(wls), d["wls"])
+
+
+def test_many_games_vs_oracle():
+    """64 games from random mid-game positions, 200 simulations, two plies with
+    tree reuse and host-drawn noise: every root statistic equals the oracle's."""
+    from gpu_backend import EngineBackend
+    nG, S = 64, 200
+    w, b, t, win = orc.random_positions(4000, seed=5)
+    live = [i for i in range(4000) if win[i] == 0 and orc.legal_actions(orc.make_pos(w[i], b[i], t[i])).size][:: 4000 // nG][:nG]
+    ev = TableEvaluator()
+    dev, cpu = EngineBackend(nG, pool_nodes_per_game=1 << 16), orc.OracleMCTS(nG)
+    for j, i in enumerate(live):
+        p = orc.make_pos(w[i], b[i], t[i])
+        dev.set_game(j, p); cpu.set_game(j, p)
+    rs = np.random.RandomState(0)
+    alive = np.ones(nG, bool)
+    for ply in range(3):
+        dev.set_active(alive); cpu.set_active(alive)
+        noise = rs.dirichlet([0.35] * 48, size=nG)
+        dev.search(ev, S, noise=noise); cpu.search(ev, S, noise=noise)
+        for j in range(nG):
+            if not alive[j]:
+                continue
+            a, o = dev.root_children(j), cpu.root_children(j)
+            assert np.array_equal(a["actions"], o["actions"])
+            assert np.array_equal(a["N"], o["N"])
+            assert np.array_equal(a["W"].view(np.uint32), o["W"].view(np.uint32))
+            assert np.array_equal(a["P"].view(np.uint64), o["P"].view(np.uint64))
+            assert a["root_N"] == o["root_N"]
+            assert np.array_equal(dev.action_probs(j, 1.0).view(np.uint32), cpu.action_probs(j, 1.0).view(np.uint32))
+            assert np.array_equal(dev.action_probs(j, 0.0), cpu.action_probs(j, 0.0))
+            act = int(o["actions"][np.argmax(o["N"])])
+            dev.advance(j, act); cpu.advance(j, act)
+            if orc.is_terminal(cpu.get_game(j)):
+                alive[j] = False
+    assert abs(dev.mean_depth() - cpu.mean_depth()) < 1e-9
