@@ -73,7 +73,7 @@ _OPTIONAL = {
     "az_net_create": [C.POINTER(_VP), C.POINTER(NetConfig)],
     "az_net_destroy": [_VP],
     "az_net_load_state": [_VP, _VP, C.c_int64],
-    "az_net_forward": [_VP, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP],
+    "az_net_forward": [_VP, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, _VP],
     "az_net_forward_planes": [_VP, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP],
     "az_net_layer_time": [_VP],
     "az_engine_attach_net": [_VP, _VP],

@@ -1,0 +1,755 @@
+// Batched SE-ResNet (N blocks x 128 filters) inference for gfx950, bf16 MFMA.
+// Reference semantics: AlphaZeroNet.forward (src/model.py:144-180),
+// SEResidualBlock (:75-92), SEBlock (:37-53), and the softmax / value recipe of
+// MCTS._batch_evaluate (src/mcts.py:252-256).
+//
+// One forward = three launches:
+//   k_tower       stem + every residual block + policy conv + value conv, fused.
+//                 A workgroup of 4 waves owns 4 positions; each wave owns ONE
+//                 position (64 pixels x 128 channels) for the whole network.
+//                 Activations never leave the CU: the current layer input lives
+//                 in the wave's private LDS region ([64 px][128 ch] bf16, 272-byte
+//                 pixel pitch so that ds_read_b128 fragment reads are conflict
+//                 free), the residual stays in registers, and only the folded
+//                 weights stream in (L2 -> LDS by global_load_lds, one 32 KB tap
+//                 at a time, double buffered, stored in MFMA fragment order so the
+//                 LDS image is lane-linear).
+//                 3x3 conv = 9 taps x 8 k-steps of v_mfma_f32_32x32x16_bf16 with
+//                 D[channel][pixel] = W[channel][k] * X[k][pixel]; a tap is just a
+//                 per-lane LDS address (out-of-board pixels read a zero row).
+//   k_head_gemm   policy FC (8192->192) and value FC1 (2048->128) as split-K MFMA
+//                 GEMMs over the bf16 head activations.
+//   k_head_finish bias, ReLU, value FC2, both softmaxes, value = P(win) - P(loss).
+//
+// BatchNorm (eval mode, eps 1e-5) is folded into the conv weights and a bias at
+// load time.  Arithmetic: bf16 operands, float32 accumulation, float32 epilogues.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "az_common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((address_space(3))) void lds_void;
+
+namespace az {
+
+constexpr int CH = 128;                        // filters
+constexpr int ACT_PITCH = 272;                 // bytes per pixel row in LDS (256 + 16 pad)
+constexpr int ACT_REGION = 64 * ACT_PITCH;     // 17408 B per position
+constexpr int LDS_ZERO = 4 * ACT_REGION;       // 69632: a zeroed pixel row for out-of-board taps
+constexpr int LDS_W = LDS_ZERO + 512;          // 70144: two 32 KB weight buffers
+constexpr int TAP_BYTES = 8 * 4 * 64 * 16;     // 32768: [ks 8][nt 4][lane 64][16 B]
+constexpr int LDS_TOTAL = LDS_W + 2 * TAP_BYTES;  // 135680
+constexpr int CONV_BYTES = 9 * TAP_BYTES;      // 294912
+constexpr int VALUE_CH = 32;
+constexpr int SE_HID = 16;
+constexpr int HEAD_KCHUNK = 1024;
+constexpr int POLICY_K = 64 * CH;              // 8192
+constexpr int VALUE_K = 64 * VALUE_CH;         // 2048
+constexpr int POLICY_CHUNKS = POLICY_K / HEAD_KCHUNK;  // 8
+constexpr int VALUE_CHUNKS = VALUE_K / HEAD_KCHUNK;    // 2
+
+struct TowerParams {
+    const uint64_t* mine;       // [B] canonical bitboards
+    const uint64_t* theirs;
+    int B;
+    int blocks;
+    const uint8_t* stem_w;      // [ks 2][nt 4][lane 64][16 B]
+    const float* stem_b;        // [128]
+    const uint8_t* conv_w;      // [2*blocks+1][CONV_BYTES]; the last one is the policy conv
+    const float* conv_b;        // [2*blocks+1][128]
+    const float* se_w1;         // [blocks][16][128]
+    const float* se_b1;         // [blocks][16]
+    const float* se_w2;         // [blocks][256][16]
+    const float* se_b2;         // [blocks][256]
+    const uint8_t* value_w;     // [ks 8][lane 64][16 B]
+    const float* value_b;       // [32]
+    __bf16* p_act;              // [B][64 px][128 ch]
+    __bf16* v_act;              // [B][64 px][32 ch]
+};
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    bf16x2 v = {(__bf16)a, (__bf16)b};
+    return *reinterpret_cast<uint32_t*>(&v);
+}
+__device__ __forceinline__ float bf16_lo(uint32_t v) { return __uint_as_float(v << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t v) { return __uint_as_float(v & 0xFFFF0000u); }
+
+// orders this wave's LDS writes before its later LDS reads by other lanes
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ bf16x8 lds_read_frag(const char* lds, uint32_t off) {
+    return *reinterpret_cast<const bf16x8*>(lds + off);
+}
+
+// acc[nt][pt][v] + bias -> optional ReLU -> bf16 -> the wave's LDS region, and
+// (optionally) the packed copy kept in registers as the next residual.
+template <bool RELU, bool KEEP>
+__device__ __forceinline__ void store_act(char* region, const f32x16 (&acc)[4][2],
+                                          const float* bias, uint32_t (&keep)[4][2][8], int r,
+                                          int h) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int ch0 = nt * 32 + gq * 8 + h * 4;
+            const f32x4 b = *reinterpret_cast<const f32x4*>(bias + ch0);
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                float v0 = acc[nt][pt][gq * 4 + 0] + b[0];
+                float v1 = acc[nt][pt][gq * 4 + 1] + b[1];
+                float v2 = acc[nt][pt][gq * 4 + 2] + b[2];
+                float v3 = acc[nt][pt][gq * 4 + 3] + b[3];
+                if (RELU) {
+                    v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+                }
+                const uint32_t lo = pack_bf16x2(v0, v1), hi = pack_bf16x2(v2, v3);
+                if (KEEP) { keep[nt][pt][gq * 2 + 0] = lo; keep[nt][pt][gq * 2 + 1] = hi; }
+                *reinterpret_cast<uint2*>(region + (pt * 32 + r) * ACT_PITCH + ch0 * 2) = make_uint2(lo, hi);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
+    __shared__ __attribute__((aligned(1024))) char lds[LDS_TOTAL];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 31, h = lane >> 5;
+    const int pos = blockIdx.x * 4 + wave;
+    const bool live = pos < p.B;
+    char* region = lds + wave * ACT_REGION;
+    const int nconv = 2 * p.blocks + 1;
+    const int total_taps = nconv * 9;
+
+    // zero row for out-of-board taps
+    for (int i = tid; i < 512 / 4; i += 256) reinterpret_cast<uint32_t*>(lds + LDS_ZERO)[i] = 0;
+
+    // weight stream: tap T of the conv sequence -> buffer T&1; each wave copies 8 KB
+    auto prefetch = [&](int T) {
+        const uint8_t* src = p.conv_w + (size_t)T * TAP_BYTES + wave * 8192 + lane * 16;
+        char* dst = lds + LDS_W + (T & 1) * TAP_BYTES + wave * 8192;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_global_load_lds((const void*)(src + i * 1024), (lds_void*)(dst + i * 1024), 16, 0, 0);
+    };
+    prefetch(0);
+
+    // per-tap fragment addresses (bytes from the LDS base) for the two pixel tiles
+    uint32_t aaddr[9][2];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const int px = pt * 32 + r;
+            const int y = (px >> 3) + dy, x = (px & 7) + dx;
+            const bool ok = (y >= 0) && (y < 8) && (x >= 0) && (x < 8);
+            aaddr[tap][pt] = ok ? (uint32_t)(wave * ACT_REGION + (y * 8 + x) * ACT_PITCH + h * 16)
+                                : (uint32_t)(LDS_ZERO + h * 16);
+        }
+    }
+
+    f32x16 acc[4][2];
+    uint32_t resid[4][2][8];
+
+    // ---------------- stem: 3x3 conv over the 3 input planes, K = 27 padded to 32
+    {
+        const uint64_t mine = live ? p.mine[pos] : 0ull, theirs = live ? p.theirs[pos] : 0ull;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[nt][pt][v] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 xb[2];
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                const int px = pt * 32 + r;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = ks * 16 + h * 8 + j;  // k = tap*3 + plane
+                    const int tap = k / 3, pl = k - tap * 3;
+                    const int y = (px >> 3) + tap / 3 - 1, x = (px & 7) + tap % 3 - 1;
+                    const bool ok = (k < 27) && (y >= 0) && (y < 8) && (x >= 0) && (x < 8);
+                    const int sq = (y * 8 + x) & 63;
+                    const uint64_t src = (pl == 0) ? mine : ((pl == 1) ? theirs : ~0ull);
+                    xb[pt][j] = (__bf16)((ok && ((src >> sq) & 1ull)) ? 1.0f : 0.0f);
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const bf16x8 w = *reinterpret_cast<const bf16x8*>(p.stem_w + ((ks * 4 + nt) * 64 + lane) * 16);
+                acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, xb[0], acc[nt][0], 0, 0, 0);
+                acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, xb[1], acc[nt][1], 0, 0, 0);
+            }
+        }
+        store_act<true, true>(region, acc, p.stem_b, resid, r, h);
+    }
+    __syncthreads();  // tap 0 landed (the compiler drains vmcnt here), zero row visible
+
+    for (int conv = 0; conv < nconv; ++conv) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[nt][pt][v] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int T = conv * 9 + tap;
+            if (T + 1 < total_taps) prefetch(T + 1);
+            const uint32_t wb = LDS_W + (T & 1) * TAP_BYTES + lane * 16;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const bf16x8 x0 = lds_read_frag(lds, aaddr[tap][0] + ks * 32);
+                const bf16x8 x1 = lds_read_frag(lds, aaddr[tap][1] + ks * 32);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const bf16x8 w = lds_read_frag(lds, wb + (ks * 4 + nt) * 1024);
+                    acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x0, acc[nt][0], 0, 0, 0);
+                    acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x1, acc[nt][1], 0, 0, 0);
+                }
+            }
+            __syncthreads();  // next tap landed; everyone is done with this buffer
+        }
+        const float* bias = p.conv_b + conv * CH;
+        if (conv == nconv - 1) {
+            // ---- policy conv: + bias, ReLU -> LDS -> p_act (coalesced 16 B per lane)
+            store_act<true, false>(region, acc, bias, resid, r, h);
+            if (live) {
+                char* out = reinterpret_cast<char*>(p.p_act) + (size_t)pos * 64 * CH * 2;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int idx = i * 64 + lane;  // 16-byte granule: pixel idx/16, part idx%16
+                    const uint4 v = *reinterpret_cast<const uint4*>(region + (idx >> 4) * ACT_PITCH + (idx & 15) * 16);
+                    *reinterpret_cast<uint4*>(out + idx * 16) = v;
+                }
+            }
+        } else if ((conv & 1) == 0) {
+            // ---- conv1 of a block: + bias, ReLU -> LDS
+            store_act<true, false>(region, acc, bias, resid, r, h);
+        } else {
+            // ---- conv2 of a block: + bias, SE, + residual, ReLU -> LDS and registers
+            const int blk = conv >> 1;
+            float* scratch = reinterpret_cast<float*>(region);  // the region is free now
+            // z = acc + bias; channel sums over the 64 pixels
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int ch0 = nt * 32 + gq * 8 + h * 4;
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(bias + ch0);
+                    f32x4 s;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc[nt][0][gq * 4 + q] += b[q];
+                        acc[nt][1][gq * 4 + q] += b[q];
+                        float t = acc[nt][0][gq * 4 + q] + acc[nt][1][gq * 4 + q];
+#pragma unroll
+                        for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o);
+                        s[q] = t * (1.0f / 64.0f);
+                    }
+                    if (r == 0) *reinterpret_cast<f32x4*>(scratch + ch0) = s;  // means[128]
+                }
+            }
+            wave_lds_sync();
+            // fc1 (128 -> 16) + ReLU: lane = (j = lane&15, quarter = lane>>4)
+            {
+                const int j = lane & 15, q4 = lane >> 4;
+                const float* w1 = p.se_w1 + ((size_t)blk * SE_HID + j) * CH + q4 * 32;
+                float y = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(w1 + i * 4);
+                    const f32x4 m = *reinterpret_cast<const f32x4*>(scratch + q4 * 32 + i * 4);
+                    y += w[0] * m[0] + w[1] * m[1] + w[2] * m[2] + w[3] * m[3];
+                }
+                y += __shfl_xor(y, 16);
+                y += __shfl_xor(y, 32);
+                y = fmaxf(y + p.se_b1[blk * SE_HID + j], 0.f);
+                if (lane < 16) scratch[128 + lane] = y;  // hidden[16]
+            }
+            wave_lds_sync();
+            // fc2 (16 -> 256): lane computes outputs lane + 64*m
+            {
+                f32x4 hid[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hid[i] = *reinterpret_cast<const f32x4*>(scratch + 128 + i * 4);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int o = lane + 64 * m;
+                    const float* w2 = p.se_w2 + ((size_t)blk * 2 * CH + o) * SE_HID;
+                    float s = p.se_b2[blk * 2 * CH + o];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(w2 + i * 4);
+                        s += w[0] * hid[i][0] + w[1] * hid[i][1] + w[2] * hid[i][2] + w[3] * hid[i][3];
+                    }
+                    if (m < 2) s = 1.0f / (1.0f + __expf(-s));  // sigmoid gate for channels 0..127
+                    scratch[160 + o] = s;                        // gate[128], shift[128]
+                }
+            }
+            wave_lds_sync();
+            // out = relu(z * gate + shift + residual)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int ch0 = nt * 32 + gq * 8 + h * 4;
+                    const f32x4 gt = *reinterpret_cast<const f32x4*>(scratch + 160 + ch0);
+                    const f32x4 sh = *reinterpret_cast<const f32x4*>(scratch + 160 + CH + ch0);
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt) {
+                        const uint32_t rlo = resid[nt][pt][gq * 2 + 0], rhi = resid[nt][pt][gq * 2 + 1];
+                        acc[nt][pt][gq * 4 + 0] = acc[nt][pt][gq * 4 + 0] * gt[0] + sh[0] + bf16_lo(rlo);
+                        acc[nt][pt][gq * 4 + 1] = acc[nt][pt][gq * 4 + 1] * gt[1] + sh[1] + bf16_hi(rlo);
+                        acc[nt][pt][gq * 4 + 2] = acc[nt][pt][gq * 4 + 2] * gt[2] + sh[2] + bf16_lo(rhi);
+                        acc[nt][pt][gq * 4 + 3] = acc[nt][pt][gq * 4 + 3] * gt[3] + sh[3] + bf16_hi(rhi);
+                    }
+                }
+            }
+            store_act<true, true>(region, acc, p.conv_b + (size_t)nconv * CH /* zeros */, resid, r, h);
+            if (conv == nconv - 2) {
+                // ---- value head conv 1x1 (128 -> 32) on the tower output, + bias, ReLU -> v_act
+                f32x16 va[2];
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) va[pt][v] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const bf16x8 w = *reinterpret_cast<const bf16x8*>(p.value_w + (ks * 64 + lane) * 16);
+                    const bf16x8 x0 = lds_read_frag(lds, aaddr[4][0] + ks * 32);
+                    const bf16x8 x1 = lds_read_frag(lds, aaddr[4][1] + ks * 32);
+                    va[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x0, va[0], 0, 0, 0);
+                    va[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x1, va[1], 0, 0, 0);
+                }
+                if (live) {
+                    char* out = reinterpret_cast<char*>(p.v_act) + (size_t)pos * 64 * VALUE_CH * 2;
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int ch0 = gq * 8 + h * 4;
+                        const f32x4 b = *reinterpret_cast<const f32x4*>(p.value_b + ch0);
+#pragma unroll
+                        for (int pt = 0; pt < 2; ++pt) {
+                            const float v0 = fmaxf(va[pt][gq * 4 + 0] + b[0], 0.f);
+                            const float v1 = fmaxf(va[pt][gq * 4 + 1] + b[1], 0.f);
+                            const float v2 = fmaxf(va[pt][gq * 4 + 2] + b[2], 0.f);
+                            const float v3 = fmaxf(va[pt][gq * 4 + 3] + b[3], 0.f);
+                            *reinterpret_cast<uint2*>(out + ((pt * 32 + r) * VALUE_CH + ch0) * 2) =
+                                make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Head GEMMs: out_part[chunk][pos][N] = act[pos][chunk K-range] . W[n][same K-range]
+// v_mfma_f32_16x16x32_bf16, 16 positions per workgroup, wave w owns NTW n-tiles.
+struct HeadParams {
+    const __bf16* p_act;   // [B][8192]
+    const __bf16* v_act;   // [B][2048]
+    const uint8_t* wp;     // policy FC, [kstep 256][ntile 12][lane 64][16 B]
+    const uint8_t* wv;     // value FC1, [kstep 64][ntile 8][lane 64][16 B]
+    float* part_p;         // [8][B][192]
+    float* part_v;         // [2][B][128]
+    int B;
+};
+
+template <int NTW, int NTILES>
+__device__ __forceinline__ void head_gemm_body(const __bf16* act, int K, const uint8_t* w, float* part,
+                                               int N, int B, int chunk, int tile, int wave, int lane) {
+    const int row = lane & 15, quarter = lane >> 4;
+    int pos = tile * 16 + row;
+    if (pos >= B) pos = B - 1;  // clamp loads; stores are masked below
+    const __bf16* arow = act + (size_t)pos * K + chunk * HEAD_KCHUNK + quarter * 8;
+    f32x4 acc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ks0 = chunk * (HEAD_KCHUNK / 32);
+#pragma unroll 4
+    for (int ks = 0; ks < HEAD_KCHUNK / 32; ++ks) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(arow + ks * 32);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int nt = wave * NTW + t;
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(w + (((size_t)(ks0 + ks) * NTILES + nt) * 64 + lane) * 16);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int n = (wave * NTW + t) * 16 + (lane & 15);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int pp = tile * 16 + (lane >> 4) * 4 + v;
+            if (pp < B) part[((size_t)chunk * B + pp) * N + n] = acc[t][v];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_head_gemm(HeadParams p) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tile = blockIdx.x, c = blockIdx.y;
+    if (c < POLICY_CHUNKS)
+        head_gemm_body<3, 12>(p.p_act, POLICY_K, p.wp, p.part_p, NUM_ACTIONS, p.B, c, tile, wave, lane);
+    else
+        head_gemm_body<2, 8>(p.v_act, VALUE_K, p.wv, p.part_v, 128, p.B, c - POLICY_CHUNKS, tile, wave, lane);
+}
+
+struct FinishParams {
+    const float* part_p; const float* part_v;
+    const float* bp;   // [192]
+    const float* bv1;  // [128]
+    const float* wv2;  // [2][128]
+    const float* bv2;  // [2]
+    float* probs; float* value; float* policy_logits; float* wl_logits;
+    int B;
+};
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// one wave per position
+__global__ __launch_bounds__(256) void k_head_finish(FinishParams p) {
+    const int lane = threadIdx.x & 63;
+    const int pos = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pos >= p.B) return;
+    float lg[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int n = lane + 64 * i;
+        float s = p.bp[n];
+#pragma unroll
+        for (int c = 0; c < POLICY_CHUNKS; ++c) s += p.part_p[((size_t)c * p.B + pos) * NUM_ACTIONS + n];
+        lg[i] = s;
+        if (p.policy_logits) p.policy_logits[(size_t)pos * NUM_ACTIONS + n] = s;
+    }
+    const float mx = wave_max(fmaxf(lg[0], fmaxf(lg[1], lg[2])));
+    float e[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) e[i] = __expf(lg[i] - mx);
+    const float inv = 1.0f / wave_sum(e[0] + e[1] + e[2]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) p.probs[(size_t)pos * NUM_ACTIONS + lane + 64 * i] = e[i] * inv;
+    // value head: hidden = relu(fc1), wl = fc2(hidden)
+    float w0 = 0.f, w1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int n = lane + 64 * i;
+        float s = p.bv1[n];
+#pragma unroll
+        for (int c = 0; c < VALUE_CHUNKS; ++c) s += p.part_v[((size_t)c * p.B + pos) * 128 + n];
+        s = fmaxf(s, 0.f);
+        w0 += s * p.wv2[n];
+        w1 += s * p.wv2[128 + n];
+    }
+    w0 = wave_sum(w0) + p.bv2[0];
+    w1 = wave_sum(w1) + p.bv2[1];
+    if (lane == 0) {
+        if (p.wl_logits) { p.wl_logits[2 * pos] = w0; p.wl_logits[2 * pos + 1] = w1; }
+        const float m = fmaxf(w0, w1);
+        const float e0 = __expf(w0 - m), e1 = __expf(w1 - m);
+        const float is = 1.0f / (e0 + e1);
+        p.value[pos] = e0 * is - e1 * is;   // P(win) - P(loss), src/mcts.py:256
+    }
+}
+
+// planes [B][3][8][8] float32 (0/1 values, third plane ones) -> canonical bitboards
+__global__ void k_planes_to_bits(const float* planes, int B, uint64_t* mine, uint64_t* theirs, int32_t* bad) {
+    const int lane = threadIdx.x & 63;
+    const int pos = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (pos >= B) return;
+    const float a = planes[(size_t)pos * 192 + lane], b = planes[(size_t)pos * 192 + 64 + lane],
+                c = planes[(size_t)pos * 192 + 128 + lane];
+    const bool ok = (a == 0.f || a == 1.f) && (b == 0.f || b == 1.f) && (c == 1.f);
+    const unsigned long long m = __ballot(a == 1.f), t = __ballot(b == 1.f);
+    if (__ballot(!ok) && lane == 0) atomicOr(bad, 1);
+    if (lane == 0) { mine[pos] = m; theirs[pos] = t; }
+}
+
+}  // namespace az
+
+using namespace az;
+
+// ---------------------------------------------------------------------------
+struct az_net {
+    int blocks = 0, max_batch = 0, device = 0;
+    bool loaded = false;
+    std::vector<void*> allocs;
+    uint8_t *stem_w = nullptr, *conv_w = nullptr, *value_w = nullptr, *wp = nullptr, *wv = nullptr;
+    float *stem_b = nullptr, *conv_b = nullptr, *se_w1 = nullptr, *se_b1 = nullptr, *se_w2 = nullptr,
+          *se_b2 = nullptr, *value_b = nullptr, *bp = nullptr, *bv1 = nullptr, *wv2 = nullptr, *bv2 = nullptr;
+    __bf16 *p_act = nullptr, *v_act = nullptr;
+    float *part_p = nullptr, *part_v = nullptr;
+    uint64_t *bits_mine = nullptr, *bits_theirs = nullptr;
+    int32_t* bad = nullptr;
+};
+
+static uint16_t f32_to_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7F800000u) == 0x7F800000u && (u & 0x7FFFFFu)) return (uint16_t)((u >> 16) | 0x40);  // NaN
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+
+template <typename T>
+static int dev_alloc(az_net* n, T*& ptr, size_t count) {
+    void* p = nullptr;
+    AZ_HIP(hipMalloc(&p, count * sizeof(T)));
+    AZ_HIP(hipMemset(p, 0, count * sizeof(T)));
+    ptr = (T*)p;
+    n->allocs.push_back(p);
+    return AZ_OK;
+}
+
+extern "C" int az_net_destroy(az_net* n) {
+    if (!n) return AZ_OK;
+    for (void* p : n->allocs) (void)hipFree(p);
+    delete n;
+    return AZ_OK;
+}
+
+extern "C" int az_net_create(az_net** out, const az_net_config* cfg) {
+    AZ_CHECK_ARG(out && cfg, "az_net_create: null argument");
+    AZ_CHECK_ARG(cfg->num_filters == CH, "az_net_create: the HIP path supports num_filters == 128 only (got %d)",
+                 cfg->num_filters);
+    AZ_CHECK_ARG(cfg->se_ratio == 8, "az_net_create: the HIP path supports se_ratio == 8 only (got %d)", cfg->se_ratio);
+    AZ_CHECK_ARG(cfg->num_blocks >= 1 && cfg->num_blocks <= 64, "az_net_create: num_blocks %d out of range", cfg->num_blocks);
+    AZ_CHECK_ARG(cfg->max_batch >= 1 && cfg->max_batch <= (1 << 20), "az_net_create: max_batch %d out of range", cfg->max_batch);
+    if (cfg->device >= 0) AZ_HIP(hipSetDevice(cfg->device));
+    az_net* n = new az_net();
+    n->blocks = cfg->num_blocks;
+    n->max_batch = cfg->max_batch;
+    AZ_HIP(hipGetDevice(&n->device));
+    const size_t nb = n->blocks, nconv = 2 * nb + 1, B = n->max_batch;
+    int rc = AZ_OK;
+#define A(ptr, cnt) if (rc == AZ_OK) rc = dev_alloc(n, n->ptr, (cnt))
+    A(stem_w, 2 * 4 * 64 * 16); A(stem_b, CH);
+    A(conv_w, nconv * CONV_BYTES); A(conv_b, (nconv + 1) * CH);  // + one zero row
+    A(se_w1, nb * SE_HID * CH); A(se_b1, nb * SE_HID); A(se_w2, nb * 2 * CH * SE_HID); A(se_b2, nb * 2 * CH);
+    A(value_w, 8 * 64 * 16); A(value_b, VALUE_CH);
+    A(wp, (size_t)(POLICY_K / 32) * 12 * 64 * 16); A(bp, NUM_ACTIONS);
+    A(wv, (size_t)(VALUE_K / 32) * 8 * 64 * 16); A(bv1, 128); A(wv2, 256); A(bv2, 2);
+    A(p_act, B * POLICY_K); A(v_act, B * VALUE_K);
+    A(part_p, (size_t)POLICY_CHUNKS * B * NUM_ACTIONS); A(part_v, (size_t)VALUE_CHUNKS * B * 128);
+    A(bits_mine, B); A(bits_theirs, B); A(bad, 1);
+#undef A
+    if (rc != AZ_OK) { az_net_destroy(n); return rc; }
+    *out = n;
+    return AZ_OK;
+}
+
+namespace {
+struct Folded { std::vector<float> scale, bias; };
+// eval-mode BatchNorm2d(eps=1e-5): y = (x - mean) / sqrt(var + eps) * gamma + beta
+Folded fold_bn(const float* gamma, const float* beta, const float* mean, const float* var, int n) {
+    Folded f;
+    f.scale.resize(n); f.bias.resize(n);
+    for (int i = 0; i < n; ++i) {
+        const float s = gamma[i] / std::sqrt(var[i] + 1e-5f);
+        f.scale[i] = s;
+        f.bias[i] = beta[i] - mean[i] * s;
+    }
+    return f;
+}
+// 3x3 conv weight [128][128][3][3] (scaled per output channel) -> [tap][ks][nt][lane][8] bf16
+void pack_conv3x3(const float* w, const std::vector<float>& scale, uint16_t* out) {
+    for (int tap = 0; tap < 9; ++tap)
+        for (int ks = 0; ks < 8; ++ks)
+            for (int nt = 0; nt < 4; ++nt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int n = nt * 32 + (lane & 31), c = ks * 16 + 8 * (lane >> 5) + j;
+                        const float v = w[((size_t)n * CH + c) * 9 + tap] * scale[n];
+                        out[((((size_t)tap * 8 + ks) * 4 + nt) * 64 + lane) * 8 + j] = f32_to_bf16(v);
+                    }
+}
+template <typename T>
+int upload(T* dst, const std::vector<T>& src) {
+    AZ_HIP(hipMemcpy(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return AZ_OK;
+}
+}  // namespace
+
+extern "C" int az_net_load_state(az_net* n, const float* s, int64_t count) {
+    AZ_CHECK_ARG(n && s, "az_net_load_state: null argument");
+    const int nb = n->blocks;
+    const int64_t per_bn = 4 * CH;
+    const int64_t per_block = 2 * ((int64_t)CH * CH * 9 + per_bn) + SE_HID * CH + SE_HID + 2 * CH * SE_HID + 2 * CH;
+    const int64_t expect = (int64_t)CH * 3 * 9 + per_bn + nb * per_block + ((int64_t)CH * CH * 9 + per_bn) +
+                           (int64_t)NUM_ACTIONS * POLICY_K + NUM_ACTIONS + ((int64_t)VALUE_CH * CH + 4 * VALUE_CH) +
+                           128ll * VALUE_K + 128 + 256 + 2;
+    AZ_CHECK_ARG(count == expect, "az_net_load_state: got %lld floats, a %d x 128 network has %lld", (long long)count,
+                 nb, (long long)expect);
+    AZ_HIP(hipSetDevice(n->device));
+    const float* q = s;
+    auto take = [&](int64_t k) { const float* r = q; q += k; return r; };
+    int rc;
+    // stem
+    {
+        const float* w = take((int64_t)CH * 27);
+        const float *g = take(CH), *b = take(CH), *m = take(CH), *v = take(CH);
+        const Folded f = fold_bn(g, b, m, v, CH);
+        std::vector<uint16_t> pk(2 * 4 * 64 * 8, 0);
+        for (int ks = 0; ks < 2; ++ks)
+            for (int nt = 0; nt < 4; ++nt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = ks * 16 + 8 * (lane >> 5) + j, o = nt * 32 + (lane & 31);
+                        float val = 0.f;
+                        if (k < 27) { const int tap = k / 3, pl = k % 3; val = w[((size_t)o * 3 + pl) * 9 + tap] * f.scale[o]; }
+                        pk[(((size_t)ks * 4 + nt) * 64 + lane) * 8 + j] = f32_to_bf16(val);
+                    }
+        if ((rc = upload((uint16_t*)n->stem_w, pk))) return rc;
+        if ((rc = upload(n->stem_b, f.bias))) return rc;
+    }
+    // tower
+    std::vector<uint16_t> convs((size_t)(2 * nb + 1) * CONV_BYTES / 2);
+    std::vector<float> conv_b((size_t)(2 * nb + 2) * CH, 0.f);
+    std::vector<float> w1((size_t)nb * SE_HID * CH), b1((size_t)nb * SE_HID), w2((size_t)nb * 2 * CH * SE_HID), b2((size_t)nb * 2 * CH);
+    for (int blk = 0; blk < nb; ++blk) {
+        for (int half = 0; half < 2; ++half) {
+            const float* w = take((int64_t)CH * CH * 9);
+            const float *g = take(CH), *b = take(CH), *m = take(CH), *v = take(CH);
+            const Folded f = fold_bn(g, b, m, v, CH);
+            const int ci = blk * 2 + half;
+            pack_conv3x3(w, f.scale, convs.data() + (size_t)ci * CONV_BYTES / 2);
+            memcpy(&conv_b[(size_t)ci * CH], f.bias.data(), CH * sizeof(float));
+        }
+        memcpy(&w1[(size_t)blk * SE_HID * CH], take(SE_HID * CH), SE_HID * CH * sizeof(float));
+        memcpy(&b1[(size_t)blk * SE_HID], take(SE_HID), SE_HID * sizeof(float));
+        memcpy(&w2[(size_t)blk * 2 * CH * SE_HID], take(2 * CH * SE_HID), 2 * CH * SE_HID * sizeof(float));
+        memcpy(&b2[(size_t)blk * 2 * CH], take(2 * CH), 2 * CH * sizeof(float));
+    }
+    // policy head
+    {
+        const float* w = take((int64_t)CH * CH * 9);
+        const float *g = take(CH), *b = take(CH), *m = take(CH), *v = take(CH);
+        const Folded f = fold_bn(g, b, m, v, CH);
+        pack_conv3x3(w, f.scale, convs.data() + (size_t)(2 * nb) * CONV_BYTES / 2);
+        memcpy(&conv_b[(size_t)(2 * nb) * CH], f.bias.data(), CH * sizeof(float));
+        const float* fc = take((int64_t)NUM_ACTIONS * POLICY_K);
+        const float* fb = take(NUM_ACTIONS);
+        // [kstep][ntile 12][lane][8]: n = nt*16 + (lane&15), k' = kstep*32 + 8*(lane>>4) + j,
+        // k' = px*128 + c  <->  reference flatten index c*64 + px (src/model.py:168)
+        std::vector<uint16_t> pk((size_t)(POLICY_K / 32) * 12 * 64 * 8);
+        for (int ks = 0; ks < POLICY_K / 32; ++ks)
+            for (int nt = 0; nt < 12; ++nt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int o = nt * 16 + (lane & 15), k = ks * 32 + 8 * (lane >> 4) + j;
+                        const int px = k / CH, c = k % CH;
+                        pk[(((size_t)ks * 12 + nt) * 64 + lane) * 8 + j] = f32_to_bf16(fc[(size_t)o * POLICY_K + c * 64 + px]);
+                    }
+        if ((rc = upload((uint16_t*)n->wp, pk))) return rc;
+        if ((rc = upload(n->bp, std::vector<float>(fb, fb + NUM_ACTIONS)))) return rc;
+    }
+    // value head
+    {
+        const float* w = take((int64_t)VALUE_CH * CH);
+        const float *g = take(VALUE_CH), *b = take(VALUE_CH), *m = take(VALUE_CH), *v = take(VALUE_CH);
+        const Folded f = fold_bn(g, b, m, v, VALUE_CH);
+        std::vector<uint16_t> pk(8 * 64 * 8);
+        for (int ks = 0; ks < 8; ++ks)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int o = lane & 31, c = ks * 16 + 8 * (lane >> 5) + j;
+                    pk[((size_t)ks * 64 + lane) * 8 + j] = f32_to_bf16(w[(size_t)o * CH + c] * f.scale[o]);
+                }
+        if ((rc = upload((uint16_t*)n->value_w, pk))) return rc;
+        if ((rc = upload(n->value_b, f.bias))) return rc;
+        const float* fc1 = take(128ll * VALUE_K);
+        const float* fb1 = take(128);
+        std::vector<uint16_t> pv((size_t)(VALUE_K / 32) * 8 * 64 * 8);
+        for (int ks = 0; ks < VALUE_K / 32; ++ks)
+            for (int nt = 0; nt < 8; ++nt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int o = nt * 16 + (lane & 15), k = ks * 32 + 8 * (lane >> 4) + j;
+                        const int px = k / VALUE_CH, c = k % VALUE_CH;
+                        pv[(((size_t)ks * 8 + nt) * 64 + lane) * 8 + j] = f32_to_bf16(fc1[(size_t)o * VALUE_K + c * 64 + px]);
+                    }
+        if ((rc = upload((uint16_t*)n->wv, pv))) return rc;
+        if ((rc = upload(n->bv1, std::vector<float>(fb1, fb1 + 128)))) return rc;
+        const float* fc2 = take(256);
+        const float* fb2 = take(2);
+        if ((rc = upload(n->wv2, std::vector<float>(fc2, fc2 + 256)))) return rc;
+        if ((rc = upload(n->bv2, std::vector<float>(fb2, fb2 + 2)))) return rc;
+    }
+    if (q - s != count) AZ_FAIL(AZ_ERR_ARG, "az_net_load_state: internal layout mismatch");
+    if ((rc = upload((uint16_t*)n->conv_w, convs))) return rc;
+    if ((rc = upload(n->conv_b, conv_b))) return rc;
+    if ((rc = upload(n->se_w1, w1))) return rc;
+    if ((rc = upload(n->se_b1, b1))) return rc;
+    if ((rc = upload(n->se_w2, w2))) return rc;
+    if ((rc = upload(n->se_b2, b2))) return rc;
+    n->loaded = true;
+    return AZ_OK;
+}
+
+extern "C" int az_net_forward(az_net* n, int32_t B, const uint64_t* mine_dev, const uint64_t* theirs_dev,
+                              float* probs_dev, float* value_dev, float* policy_logits_dev,
+                              float* wl_logits_dev, void* stream) {
+    AZ_CHECK_ARG(n && n->loaded, "az_net_forward: network has no weights (call az_net_load_state)");
+    AZ_CHECK_ARG(B >= 0 && B <= n->max_batch, "az_net_forward: batch %d exceeds max_batch %d", B, n->max_batch);
+    if (B == 0) return AZ_OK;
+    AZ_CHECK_ARG(mine_dev && theirs_dev && probs_dev && value_dev, "az_net_forward: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    TowerParams tp;
+    tp.mine = mine_dev; tp.theirs = theirs_dev; tp.B = B; tp.blocks = n->blocks;
+    tp.stem_w = n->stem_w; tp.stem_b = n->stem_b; tp.conv_w = n->conv_w; tp.conv_b = n->conv_b;
+    tp.se_w1 = n->se_w1; tp.se_b1 = n->se_b1; tp.se_w2 = n->se_w2; tp.se_b2 = n->se_b2;
+    tp.value_w = n->value_w; tp.value_b = n->value_b; tp.p_act = n->p_act; tp.v_act = n->v_act;
+    hipLaunchKernelGGL(k_tower, dim3((B + 3) / 4), dim3(256), 0, s, tp);
+    HeadParams hp{n->p_act, n->v_act, n->wp, n->wv, n->part_p, n->part_v, B};
+    hipLaunchKernelGGL(k_head_gemm, dim3((B + 15) / 16, POLICY_CHUNKS + VALUE_CHUNKS), dim3(256), 0, s, hp);
+    FinishParams fp{n->part_p, n->part_v, n->bp, n->bv1, n->wv2, n->bv2, probs_dev, value_dev,
+                    policy_logits_dev, wl_logits_dev, B};
+    hipLaunchKernelGGL(k_head_finish, dim3((B + 3) / 4), dim3(256), 0, s, fp);
+    AZ_HIP(hipGetLastError());
+    return AZ_OK;
+}
+
+extern "C" int az_net_forward_planes(az_net* n, int32_t B, const float* planes_dev, float* probs_dev,
+                                     float* value_dev, float* policy_logits_dev, float* wl_logits_dev,
+                                     void* stream) {
+    AZ_CHECK_ARG(n && n->loaded, "az_net_forward_planes: network has no weights");
+    AZ_CHECK_ARG(B >= 0 && B <= n->max_batch, "az_net_forward_planes: batch %d exceeds max_batch %d", B, n->max_batch);
+    if (B == 0) return AZ_OK;
+    AZ_CHECK_ARG(planes_dev, "az_net_forward_planes: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    AZ_HIP(hipMemsetAsync(n->bad, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_planes_to_bits, dim3((B + 3) / 4), dim3(256), 0, s, planes_dev, B, n->bits_mine,
+                       n->bits_theirs, n->bad);
+    const int rc = az_net_forward(n, B, n->bits_mine, n->bits_theirs, probs_dev, value_dev, policy_logits_dev,
+                                  wl_logits_dev, stream);
+    if (rc != AZ_OK) return rc;
+    int32_t bad = 0;
+    AZ_HIP(hipMemcpyAsync(&bad, n->bad, sizeof bad, hipMemcpyDeviceToHost, s));
+    AZ_HIP(hipStreamSynchronize(s));
+    if (bad) AZ_FAIL(AZ_ERR_ARG, "az_net_forward_planes: input is not an encoded Breakthrough state "
+                                 "(planes 0/1 must hold 0 or 1, plane 2 must be all ones)");
+    return AZ_OK;
+}

@@ -53,6 +53,43 @@ int az_movegen_encode(int64_t n, const uint64_t* white_dev, const uint64_t* blac
                       float* planes_dev, int8_t* status_dev, void* stream);
 
 /* ------------------------------------------------------------------------
+ * SE-ResNet inference (bf16 MFMA).  Replaces AlphaZeroNet.forward in eval mode
+ * (src/model.py:144-180) together with the softmax / value recipe of
+ * MCTS._batch_evaluate (src/mcts.py:248-256).
+ */
+typedef struct az_net az_net;
+
+typedef struct {
+    int32_t num_blocks;   /* src/config.py:26 */
+    int32_t num_filters;  /* src/config.py:27; the HIP path supports 128 */
+    int32_t se_ratio;     /* src/config.py:28; the HIP path supports 8 */
+    int32_t max_batch;
+    int32_t device;       /* HIP device ordinal, -1 = current */
+} az_net_config;
+
+int az_net_create(az_net** out, const az_net_config* cfg);
+int az_net_destroy(az_net* n);
+/* state_host: every floating-point tensor of AlphaZeroNet.state_dict()
+ * (src/model.py:123-142), flattened and concatenated in state_dict order
+ * (num_batches_tracked entries skipped), float32, `count` floats in total.
+ * BatchNorm is folded (eval mode) and the weights are re-laid-out for the MFMA
+ * kernels here; call again after every training step that changes the weights. */
+int az_net_load_state(az_net* n, const float* state_host, int64_t count);
+/* mine_dev / theirs_dev [B] u64 canonical bitboards (planes 0 and 1 of
+ * src/game.py:280-307; plane 2 is implicit).  Outputs: probs_dev [B][192]
+ * softmaxed policy, value_dev [B] = P(win) - P(loss); the raw logits
+ * (policy_logits_dev [B][192], wl_logits_dev [B][2]) are optional (NULL). */
+int az_net_forward(az_net* n, int32_t B, const uint64_t* mine_dev, const uint64_t* theirs_dev,
+                   float* probs_dev, float* value_dev, float* policy_logits_dev,
+                   float* wl_logits_dev, void* stream);
+/* Same, from the reference's float planes [B][3][8][8]; fails with AZ_ERR_ARG
+ * if the input is not an encoded state (0/1 planes, third plane all ones).
+ * Synchronises the stream. */
+int az_net_forward_planes(az_net* n, int32_t B, const float* planes_dev, float* probs_dev,
+                          float* value_dev, float* policy_logits_dev, float* wl_logits_dev,
+                          void* stream);
+
+/* ------------------------------------------------------------------------
  * Search engine: B independent games, one tree each, nodes in an SoA pool in
  * HBM, one wavefront per game.  Replaces MCTS.search_batch and its helpers
  * (src/mcts.py:94-189, 260-342) plus the per-move bookkeeping of

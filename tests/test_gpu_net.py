@@ -1,0 +1,109 @@
+"""GPU parity, network tier: bf16 MFMA inference vs the float32 torch forward
+(same module as the reference's src/model.py) and vs logits stored by running
+the reference itself.  Tolerance (north-star): max-abs 2e-2 on policy
+probabilities and value, top-1 move agreement >= 99 %."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-2
+
+
+def randomize_bn(model, seed):
+    g = torch.Generator().manual_seed(seed)
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            n = mod.num_features
+            mod.running_mean.copy_(torch.randn(n, generator=g) * 0.1)
+            mod.running_var.copy_(torch.rand(n, generator=g) + 0.5)
+            mod.weight.data.copy_(torch.rand(n, generator=g) + 0.5)
+            mod.bias.data.copy_(torch.randn(n, generator=g) * 0.1)
+
+
+def _positions(n, seed):
+    w, b, t, win = orc.random_positions(n, seed)
+    _, _, planes, _ = orc.movegen_batch(w, b, t, want_mask=False)
+    return planes
+
+
+def _compare(model, planes, min_top1=0.99):
+    from alphazero_amd.model import HipInference
+    model.eval()
+    x = torch.from_numpy(planes)
+    with torch.no_grad():
+        pl, wl = model(x)
+        probs_ref = torch.softmax(pl, dim=1).numpy()
+        wlp = torch.softmax(wl, dim=1).numpy()
+        value_ref = wlp[:, 0] - wlp[:, 1]
+    inf = HipInference(model, max_batch=max(len(planes), 16))
+    probs, value, pl_d, wl_d = inf.forward_planes(x.cuda(), want_logits=True)
+    torch.cuda.synchronize()
+    probs, value = probs.cpu().numpy(), value.cpu().numpy()
+    err_p = np.abs(probs - probs_ref).max()
+    err_v = np.abs(value - value_ref).max()
+    err_l = np.abs(pl_d.cpu().numpy() - pl.numpy()).max()
+    top1 = (probs.argmax(1) == probs_ref.argmax(1)).mean()
+    print(f"max|dprobs|={err_p:.2e} max|dvalue|={err_v:.2e} max|dlogit|={err_l:.2e} top1={top1:.4f}")
+    assert np.allclose(probs.sum(1), 1.0, atol=1e-4)
+    assert err_p <= TOL and err_v <= TOL
+    assert top1 >= min_top1
+    return inf
+
+
+@pytest.mark.parametrize("blocks", [1, 2, 20])
+def test_forward_matches_fp32_torch(blocks):
+    from alphazero_amd.model import AlphaZeroNet
+    torch.manual_seed(0)
+    model = AlphaZeroNet(num_blocks=blocks, num_filters=128)
+    randomize_bn(model, 1)
+    _compare(model, _positions(512, seed=blocks))
+
+
+@pytest.mark.parametrize("B", [1, 3, 4, 5, 17, 1000])
+def test_ragged_batch_sizes(B):
+    from alphazero_amd.model import AlphaZeroNet
+    torch.manual_seed(3)
+    model = AlphaZeroNet(num_blocks=2, num_filters=128)
+    randomize_bn(model, 4)
+    _compare(model, _positions(B, seed=100 + B), min_top1=0.0 if B < 100 else 0.99)
+
+
+def test_matches_reference_logits_fixture(golden_dir):
+    """nn_tier.npz holds logits produced by the reference's own AlphaZeroNet
+    (torch.manual_seed(0), 20 x 128, BatchNorm statistics randomised with seed 1)."""
+    from alphazero_amd.model import AlphaZeroNet, HipInference
+    d = np.load(os.path.join(golden_dir, "nn_tier.npz"))
+    n = len(d["sel"])
+    planes = np.unpackbits(d["planes"])[: n * 192].reshape(n, 3, 8, 8).astype(np.float32)
+    torch.manual_seed(0)
+    model = AlphaZeroNet(num_blocks=20, num_filters=128)
+    randomize_bn(model, 1)
+    model.eval()
+    with torch.no_grad():
+        pl, wl = model(torch.from_numpy(planes))
+    # the drop-in module reproduces the reference module (float32, same init stream)
+    assert np.allclose(pl.numpy(), d["full_policy_logits"], atol=1e-4)
+    assert np.allclose(wl.numpy(), d["full_wl_logits"], atol=1e-4)
+    inf = HipInference(model, max_batch=64)
+    probs, value, _, _ = inf.forward_planes(torch.from_numpy(planes).cuda())
+    ref_p = torch.softmax(torch.from_numpy(d["full_policy_logits"]), 1).numpy()
+    ref_wl = torch.softmax(torch.from_numpy(d["full_wl_logits"]), 1).numpy()
+    assert np.abs(probs.cpu().numpy() - ref_p).max() <= TOL
+    assert np.abs(value.cpu().numpy() - (ref_wl[:, 0] - ref_wl[:, 1])).max() <= TOL
+
+
+def test_rejects_non_state_input():
+    from alphazero_amd.model import AlphaZeroNet, HipInference
+    from alphazero_amd._lib import AzError
+    model = AlphaZeroNet(num_blocks=1, num_filters=128)
+    inf = HipInference(model, max_batch=16)
+    with pytest.raises(AzError):
+        inf.forward_planes(torch.randn(4, 3, 8, 8).cuda())
+    with pytest.raises(AzError):
+        HipInference(AlphaZeroNet(num_blocks=1, num_filters=32))
