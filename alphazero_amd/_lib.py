@@ -68,21 +68,20 @@ _SIGNATURES = {
     "az_engine_set_root": [_VP, C.c_int32, C.c_int64, _VP],
     "az_engine_pool_usage": [_VP, _VP, _VP],
     "az_engine_stats": [_VP, _VP, _VP, _VP],
-}
-_OPTIONAL = {
     "az_net_create": [C.POINTER(_VP), C.POINTER(NetConfig)],
     "az_net_destroy": [_VP],
+    "az_net_max_batch": [_VP],
     "az_net_load_state": [_VP, _VP, C.c_int64],
     "az_net_forward": [_VP, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, _VP],
     "az_net_forward_planes": [_VP, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP],
-    "az_net_layer_time": [_VP],
     "az_engine_attach_net": [_VP, _VP],
     "az_engine_search": [_VP, C.c_int32, C.c_int32, _VP],
     "az_engine_play_move": [_VP, C.c_int32, C.c_int32, _VP, C.c_int32, _VP],
+    "az_engine_chosen_actions": [_VP, _VP, _VP],
     "az_engine_drain_samples": [_VP, C.c_int64, _VP, _VP, _VP, C.POINTER(C.c_int64), _VP],
     "az_engine_selfplay_stats": [_VP, C.POINTER(SelfplayStats), _VP],
-    "az_engine_kernel_time": [_VP, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
 }
+_OPTIONAL = {}
 
 _lib = None
 

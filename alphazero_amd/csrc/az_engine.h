@@ -25,6 +25,7 @@ struct EngineView {
     uint8_t* active;
     uint16_t* ply;
     uint32_t *root, *used;
+    uint8_t* arena;       // which of the game's two node arenas is live
     uint8_t* root_mode;   // 1: root children priors are the doubles in root_p64
     double* root_p64;     // [B][48]
     // leaf of the current simulation
@@ -58,7 +59,62 @@ struct NodeQuery {
     int64_t child_index[MAX_CHILDREN];
 };
 
+#ifdef __HIPCC__
+// counter-based generator for the device-drawn Dirichlet noise and move sampling
+__device__ inline uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+struct Rng {
+    uint64_t key, ctr;
+    __device__ Rng(uint64_t seed, uint64_t a, uint64_t b, uint64_t c)
+        : key(mix64(seed ^ mix64(a * 0x9E3779B97F4A7C15ull + b) ^ (c << 32))), ctr(0) {}
+    __device__ uint64_t next() { return mix64(key + 0x9E3779B97F4A7C15ull * (++ctr)); }
+    __device__ double uniform() { return ((double)(next() >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
+    __device__ double normal() {
+        const double u1 = uniform(), u2 = uniform();
+        return sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+    }
+    // Marsaglia-Tsang, boosted for shape < 1
+    __device__ double gamma(double a) {
+        const double boost = (a < 1.0) ? pow(uniform(), 1.0 / a) : 1.0;
+        const double aa = (a < 1.0) ? a + 1.0 : a;
+        const double d = aa - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+        for (int it = 0; it < 64; ++it) {
+            const double x = normal();
+            double v = 1.0 + c * x;
+            if (v <= 0) continue;
+            v = v * v * v;
+            const double u = uniform();
+            if (log(u) < 0.5 * x * x + d - d * v + d * log(v)) return d * v * boost;
+        }
+        return d * boost;
+    }
+};
+
+#endif
+
 enum Phase { PHASE_IDLE = 0, PHASE_ROOTS = 1, PHASE_SELECTED = 2 };
+
+constexpr int MAX_PLIES = 256;  // per-game history depth (a game lasts < 200 plies)
+
+// Self-play bookkeeping on the device (selfplay.hip): per-game move history and
+// the queue of finished training samples (src/parallel_trainer.py:185-213).
+struct SelfplayView {
+    float* pi;              // [B][192] visit-count policy of the current move
+    int16_t* chosen;        // [B] action played this move
+    uint64_t *hist_mine, *hist_theirs;  // [B][MAX_PLIES] canonical bitboards
+    int8_t* hist_turn;      // [B][MAX_PLIES]
+    float* hist_pi;         // [B][MAX_PLIES][192]
+    // finished samples, packed
+    uint64_t *q_mine, *q_theirs;  // [Q]
+    float* q_wl;            // [Q][2]
+    float* q_pi;            // [Q][192]
+    uint32_t* q_count;      // samples in the queue
+    uint32_t q_cap;
+    unsigned long long* stat;  // [0] moves, [1] games finished, [2] network evaluations
+};
 
 }  // namespace az
 
@@ -76,4 +132,16 @@ struct az_engine {
     float* stage_temps = nullptr;
     az::NodeQuery* query_dev = nullptr;
     az::NodeQuery* query_host = nullptr;
+    // fused self-play (selfplay.hip)
+    struct az_net* net = nullptr;
+    az::SelfplayView sp{};
+    bool sp_ready = false;
+    float* nn_probs = nullptr;   // [B][192]
+    float* nn_values = nullptr;  // [B]
+    uint64_t move_calls = 0;
 };
+
+namespace az {
+// tree.hip: play the actions held in a device array (same as az_engine_advance)
+int advance_dev(az_engine* e, const int16_t* actions_dev, hipStream_t s);
+}  // namespace az

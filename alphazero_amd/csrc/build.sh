@@ -11,9 +11,8 @@ pids=()
 # tree/movegen: exact float32 semantics -> no FMA contraction
 $HIPCC $COMMON -ffp-contract=off -c tree.hip -o $OBJ/tree.o & pids+=($!)
 $HIPCC $COMMON -ffp-contract=off -c movegen.hip -o $OBJ/movegen.o & pids+=($!)
-for f in net selfplay; do
-  if [ -f $f.hip ]; then $HIPCC $COMMON -c $f.hip -o $OBJ/$f.o & pids+=($!); fi
-done
+$HIPCC $COMMON -ffp-contract=off -c selfplay.hip -o $OBJ/selfplay.o & pids+=($!)
+$HIPCC $COMMON -c net.hip -o $OBJ/net.o & pids+=($!)
 g++ -O2 -fPIC -std=c++17 -c core.cpp -o $OBJ/core.o & pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJ/*.o

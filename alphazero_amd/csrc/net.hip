@@ -524,6 +524,8 @@ static int dev_alloc(az_net* n, T*& ptr, size_t count) {
     return AZ_OK;
 }
 
+extern "C" int az_net_max_batch(az_net* n) { return n ? n->max_batch : 0; }
+
 extern "C" int az_net_destroy(az_net* n) {
     if (!n) return AZ_OK;
     for (void* p : n->allocs) (void)hipFree(p);

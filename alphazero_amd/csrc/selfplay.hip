@@ -1,0 +1,286 @@
+// Fused self-play loop: search with the attached network, then the per-move
+// bookkeeping of ParallelTrainer.execute_parallel_episodes
+// (src/parallel_trainer.py:158-217) entirely on the device.
+//
+// Compile with -ffp-contract=off (shares the exact float32 rules of tree.hip).
+#include "az_engine.h"
+
+extern "C" int az_net_forward(struct az_net* n, int32_t B, const uint64_t* mine_dev,
+                              const uint64_t* theirs_dev, float* probs_dev, float* value_dev,
+                              float* policy_logits_dev, float* wl_logits_dev, void* stream);
+extern "C" int az_net_max_batch(struct az_net* n);
+
+namespace az {
+
+// Record (state, pi, turn) before moving (src/parallel_trainer.py:185-186) and
+// choose the move: np.random.choice(192, p=pi) (:189) drawn on the device, or an
+// injected action.
+__global__ __launch_bounds__(64) void k_record_and_choose(EngineView E, SelfplayView S,
+                                                          const int16_t* injected, uint64_t call_id) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (!E.active[g]) { if (lane == 0) S.chosen[g] = -1; return; }
+    const int ply = E.ply[g];
+    const float* pi = S.pi + (size_t)g * 192;
+    const float p0 = pi[3 * lane], p1 = pi[3 * lane + 1], p2 = pi[3 * lane + 2];
+    if (ply < MAX_PLIES) {
+        const size_t hrow = (size_t)g * MAX_PLIES + ply;
+        float* hp = S.hist_pi + hrow * 192;
+        hp[lane] = pi[lane]; hp[64 + lane] = pi[64 + lane]; hp[128 + lane] = pi[128 + lane];
+        if (lane == 0) {
+            const uint64_t w = E.white[g], b = E.black[g];
+            const int t = E.turn[g];
+            S.hist_mine[hrow] = (t > 0) ? w : bitrev64(b);
+            S.hist_theirs[hrow] = (t > 0) ? b : bitrev64(w);
+            S.hist_turn[hrow] = (int8_t)t;
+        }
+    } else if (lane == 0) {
+        atomicOr(E.err, ERR_HISTORY);
+    }
+    int action;
+    if (injected) {
+        action = injected[g];
+    } else {
+        // inverse-CDF draw in float64 over the 192 probabilities (numpy's choice
+        // normalises the cumulative sum by its last entry, then searches it)
+        const double d0 = (double)p0, d1 = (double)p1, d2 = (double)p2;
+        double incl = d0 + d1 + d2;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        const double total = __shfl(incl, 63);
+        const double excl = incl - (d0 + d1 + d2);
+        Rng rng(E.seed ^ 0xA5A5A5A5ull, (uint64_t)g, call_id, 0x77ull);
+        const double u = rng.uniform() * total;
+        // first index whose cumulative sum exceeds u, among entries with p > 0
+        int local = -1;
+        if (d0 > 0 && excl + d0 > u) local = 0;
+        else if (d1 > 0 && excl + d0 + d1 > u) local = 1;
+        else if (d2 > 0 && incl > u) local = 2;
+        const unsigned long long hit = __ballot(local >= 0);
+        int src;
+        if (hit) src = __ffsll((long long)hit) - 1;
+        else {  // u landed on the upper edge: take the last entry with mass
+            const unsigned long long any = __ballot(d0 + d1 + d2 > 0);
+            src = any ? 63 - __clzll((long long)any) : 0;
+            local = (d2 > 0) ? 2 : ((d1 > 0) ? 1 : 0);
+        }
+        action = __shfl(3 * lane + (local < 0 ? 0 : local), src);
+    }
+    if (lane == 0) S.chosen[g] = (int16_t)action;
+}
+
+// After the move: finished games emit their samples (src/parallel_trainer.py:201-213)
+// and either restart from the initial position or leave the active set (:216-217).
+__global__ __launch_bounds__(64) void k_finish_games(EngineView E, SelfplayView S, int restart) {
+    __shared__ uint32_t s_base;
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (!E.active[g] || S.chosen[g] < 0) return;
+    if (lane == 0) atomicAdd(&S.stat[0], 1ull);
+    const uint64_t w = E.white[g], b = E.black[g];
+    const int t = E.turn[g], win = E.winner[g];
+    bool terminal = (win != 0);
+    int white_won = (win > 0);
+    if (!terminal) {
+        const uint64_t mine = (t > 0) ? w : bitrev64(b), theirs = (t > 0) ? b : bitrev64(w);
+        const Legal3 l = legal_sources(mine, theirs);
+        if ((l.fwd | l.dl | l.dr) == 0) { terminal = true; white_won = (t < 0); }  // side to move loses
+    }
+    if (!terminal) return;
+    const int n = min((int)E.ply[g], MAX_PLIES);
+    if (lane == 0) s_base = atomicAdd(S.q_count, (uint32_t)n);
+    __syncthreads();
+    const uint32_t base = s_base;
+    if (base + (uint32_t)n > S.q_cap) {
+        if (lane == 0) { atomicOr(E.err, ERR_HISTORY); atomicSub(S.q_count, (uint32_t)n); }
+    } else {
+        const float wv = white_won ? 1.f : 0.f, lv = white_won ? 0.f : 1.f;
+        for (int i = 0; i < n; ++i) {
+            const size_t hrow = (size_t)g * MAX_PLIES + i, q = (size_t)base + i;
+            const float* hp = S.hist_pi + hrow * 192;
+            float* qp = S.q_pi + q * 192;
+            qp[lane] = hp[lane]; qp[64 + lane] = hp[64 + lane]; qp[128 + lane] = hp[128 + lane];
+            if (lane == 0) {
+                S.q_mine[q] = S.hist_mine[hrow]; S.q_theirs[q] = S.hist_theirs[hrow];
+                const bool white_moved = S.hist_turn[hrow] > 0;
+                S.q_wl[2 * q] = white_moved ? wv : lv;
+                S.q_wl[2 * q + 1] = white_moved ? lv : wv;
+            }
+        }
+    }
+    if (lane == 0) {
+        atomicAdd(&S.stat[1], 1ull);
+        if (restart) {
+            E.white[g] = 0x000000000000FFFFull; E.black[g] = 0xFFFF000000000000ull;
+            E.turn[g] = 1; E.winner[g] = 0; E.ply[g] = 0;
+            E.root[g] = NODE_NONE; E.used[g] = 0; E.root_mode[g] = 0;
+        } else {
+            E.active[g] = 0;
+        }
+    }
+}
+
+// Unpack queued samples into the reference's float layout (states [n][3][8][8],
+// policies [n][192], wls [n][2]; src/parallel_trainer.py:380-382).
+__global__ void k_unpack_samples(SelfplayView S, uint32_t n, float* states, float* policies, float* wls) {
+    const uint32_t q = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (q >= n) return;
+    const uint64_t mine = S.q_mine[q], theirs = S.q_theirs[q];
+    if (lane < 48) {
+        const int pl = lane >> 4, s0 = (4 * lane) & 63;
+        const uint64_t src = (pl == 0) ? mine : ((pl == 1) ? theirs : ~0ull);
+        float4 v;
+        v.x = (float)((src >> (s0 + 0)) & 1ull); v.y = (float)((src >> (s0 + 1)) & 1ull);
+        v.z = (float)((src >> (s0 + 2)) & 1ull); v.w = (float)((src >> (s0 + 3)) & 1ull);
+        reinterpret_cast<float4*>(states + (size_t)q * 192)[lane] = v;
+    }
+    for (int i = lane; i < 192; i += 64) policies[(size_t)q * 192 + i] = S.q_pi[(size_t)q * 192 + i];
+    if (lane < 2) wls[2 * (size_t)q + lane] = S.q_wl[2 * (size_t)q + lane];
+}
+
+__global__ void k_count_evals(EngineView E, SelfplayView S) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long c = 0;
+    if (g < E.B && E.active[g] && E.leaf_need[g]) c = 1;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&S.stat[2], c);
+}
+
+}  // namespace az
+
+using namespace az;
+
+static int selfplay_alloc(az_engine* e) {
+    if (e->sp_ready) return AZ_OK;
+    SelfplayView& S = e->sp;
+    const size_t B = e->v.B;
+    S.q_cap = (uint32_t)(B * 160 < (1u << 16) ? (1u << 16) : B * 160);
+#define AZ_ALLOC(ptr, count)                                       \
+    do {                                                           \
+        void* _p = nullptr;                                        \
+        AZ_HIP(hipMalloc(&_p, (count) * sizeof(*(ptr))));          \
+        AZ_HIP(hipMemset(_p, 0, (count) * sizeof(*(ptr))));        \
+        (ptr) = (decltype(ptr))_p;                                 \
+        e->allocs.push_back(_p);                                   \
+    } while (0)
+    AZ_ALLOC(S.pi, B * 192); AZ_ALLOC(S.chosen, B);
+    AZ_ALLOC(S.hist_mine, B * MAX_PLIES); AZ_ALLOC(S.hist_theirs, B * MAX_PLIES);
+    AZ_ALLOC(S.hist_turn, B * MAX_PLIES); AZ_ALLOC(S.hist_pi, B * MAX_PLIES * 192);
+    AZ_ALLOC(S.q_mine, (size_t)S.q_cap); AZ_ALLOC(S.q_theirs, (size_t)S.q_cap);
+    AZ_ALLOC(S.q_wl, (size_t)S.q_cap * 2); AZ_ALLOC(S.q_pi, (size_t)S.q_cap * 192);
+    AZ_ALLOC(S.q_count, 1); AZ_ALLOC(S.stat, 4);
+    AZ_ALLOC(e->nn_probs, B * 192); AZ_ALLOC(e->nn_values, B);
+#undef AZ_ALLOC
+    e->sp_ready = true;
+    return AZ_OK;
+}
+
+extern "C" int az_engine_attach_net(az_engine* e, az_net* n) {
+    AZ_CHECK_ARG(e && n, "az_engine_attach_net: null argument");
+    AZ_CHECK_ARG(az_net_max_batch(n) >= e->v.B, "az_engine_attach_net: network max_batch %d < n_games %d",
+                 az_net_max_batch(n), e->v.B);
+    e->net = n;
+    return selfplay_alloc(e);
+}
+
+static int check_sticky(az_engine* e, hipStream_t s) {
+    int32_t flag = 0;
+    AZ_HIP(hipMemcpyAsync(&flag, e->v.err, sizeof flag, hipMemcpyDeviceToHost, s));
+    AZ_HIP(hipStreamSynchronize(s));
+    if (flag & ERR_POOL) AZ_FAIL(AZ_ERR_CAPACITY, "node pool exhausted (pool_nodes_per_game = %u)", e->v.cap);
+    if (flag & ERR_DEPTH) AZ_FAIL(AZ_ERR_CAPACITY, "selection path deeper than %d", MAX_DEPTH);
+    if (flag & ERR_HISTORY) AZ_FAIL(AZ_ERR_CAPACITY, "sample queue or per-game history exhausted: drain samples more often");
+    return AZ_OK;
+}
+
+// MCTS.search_batch (src/mcts.py:94-189) with the attached network
+static int search_async(az_engine* e, int num_simulations, int add_noise, hipStream_t s) {
+    if (!e->net) AZ_FAIL(AZ_ERR_STATE, "no network attached (az_engine_attach_net)");
+    const int B = e->v.B;
+    int rc;
+    if ((rc = az_engine_roots_prepare(e, nullptr, nullptr, s))) return rc;
+    if ((rc = az_net_forward(e->net, B, e->v.leaf_mine, e->v.leaf_theirs, e->nn_probs, e->nn_values, nullptr,
+                             nullptr, s))) return rc;
+    hipLaunchKernelGGL(k_count_evals, dim3((B + 255) / 256), dim3(256), 0, s, e->v, e->sp);
+    if ((rc = az_engine_roots_expand(e, e->nn_probs, s))) return rc;
+    if (add_noise && (rc = az_engine_add_noise(e, nullptr, s))) return rc;
+    for (int i = 0; i < num_simulations; ++i) {
+        if ((rc = az_engine_select(e, nullptr, nullptr, s))) return rc;
+        if ((rc = az_net_forward(e->net, B, e->v.leaf_mine, e->v.leaf_theirs, e->nn_probs, e->nn_values,
+                                 nullptr, nullptr, s))) return rc;
+        hipLaunchKernelGGL(k_count_evals, dim3((B + 255) / 256), dim3(256), 0, s, e->v, e->sp);
+        if ((rc = az_engine_expand_backup(e, e->nn_probs, e->nn_values, s))) return rc;
+    }
+    AZ_HIP(hipGetLastError());
+    return AZ_OK;
+}
+
+extern "C" int az_engine_search(az_engine* e, int32_t num_simulations, int32_t add_noise, void* stream) {
+    AZ_CHECK_ARG(e && num_simulations >= 0, "az_engine_search: bad argument");
+    const int rc = search_async(e, num_simulations, add_noise, (hipStream_t)stream);
+    if (rc != AZ_OK) return rc;
+    return check_sticky(e, (hipStream_t)stream);
+}
+
+extern "C" int az_engine_play_move(az_engine* e, int32_t num_simulations, int32_t add_noise,
+                                   const int16_t* actions_host, int32_t restart_finished, void* stream) {
+    AZ_CHECK_ARG(e && num_simulations >= 0, "az_engine_play_move: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = search_async(e, num_simulations, add_noise, s);
+    if (rc != AZ_OK) return rc;
+    if ((rc = az_engine_action_probs(e, nullptr, e->sp.pi, s))) return rc;
+    const int16_t* inj = nullptr;
+    if (actions_host) {
+        AZ_HIP(hipMemcpyAsync(e->stage_act, actions_host, e->v.B * sizeof(int16_t), hipMemcpyHostToDevice, s));
+        inj = e->stage_act;
+    }
+    hipLaunchKernelGGL(k_record_and_choose, dim3(e->v.B), dim3(64), 0, s, e->v, e->sp, inj, ++e->move_calls);
+    if ((rc = az::advance_dev(e, e->sp.chosen, s))) return rc;
+    hipLaunchKernelGGL(k_finish_games, dim3(e->v.B), dim3(64), 0, s, e->v, e->sp, restart_finished);
+    AZ_HIP(hipGetLastError());
+    return check_sticky(e, s);
+}
+
+extern "C" int az_engine_chosen_actions(az_engine* e, int16_t* actions_host, void* stream) {
+    AZ_CHECK_ARG(e && actions_host && e->sp_ready, "az_engine_chosen_actions: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    AZ_HIP(hipMemcpyAsync(actions_host, e->sp.chosen, e->v.B * sizeof(int16_t), hipMemcpyDeviceToHost, s));
+    AZ_HIP(hipStreamSynchronize(s));
+    return AZ_OK;
+}
+
+extern "C" int az_engine_drain_samples(az_engine* e, int64_t max_samples, float* states_dev,
+                                       float* policies_dev, float* wls_dev, int64_t* n_out, void* stream) {
+    AZ_CHECK_ARG(e && n_out && e->sp_ready, "az_engine_drain_samples: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t n = 0;
+    AZ_HIP(hipMemcpyAsync(&n, e->sp.q_count, sizeof n, hipMemcpyDeviceToHost, s));
+    AZ_HIP(hipStreamSynchronize(s));
+    *n_out = n;
+    if (n == 0 || !states_dev) return AZ_OK;  // states_dev == NULL: just report the count
+    AZ_CHECK_ARG(policies_dev && wls_dev, "az_engine_drain_samples: null output");
+    AZ_CHECK_ARG((int64_t)n <= max_samples, "az_engine_drain_samples: %u samples queued, room for %lld", n,
+                 (long long)max_samples);
+    AZ_CHECK_ARG(((uintptr_t)states_dev & 15) == 0, "az_engine_drain_samples: states must be 16-byte aligned");
+    hipLaunchKernelGGL(k_unpack_samples, dim3(n), dim3(64), 0, s, e->sp, n, states_dev, policies_dev, wls_dev);
+    AZ_HIP(hipGetLastError());
+    AZ_HIP(hipMemsetAsync(e->sp.q_count, 0, sizeof(uint32_t), s));
+    AZ_HIP(hipStreamSynchronize(s));
+    return AZ_OK;
+}
+
+extern "C" int az_engine_selfplay_stats(az_engine* e, az_selfplay_stats* out, void* stream) {
+    AZ_CHECK_ARG(e && out && e->sp_ready, "az_engine_selfplay_stats: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long st[4] = {0, 0, 0, 0}, sims = 0;
+    uint32_t q = 0;
+    AZ_HIP(hipMemcpyAsync(st, e->sp.stat, sizeof st, hipMemcpyDeviceToHost, s));
+    AZ_HIP(hipMemcpyAsync(&sims, e->v.stat_descents, sizeof sims, hipMemcpyDeviceToHost, s));
+    AZ_HIP(hipMemcpyAsync(&q, e->sp.q_count, sizeof q, hipMemcpyDeviceToHost, s));
+    AZ_HIP(hipStreamSynchronize(s));
+    out->simulations = sims; out->nn_evals = st[2]; out->moves = st[0]; out->games_finished = st[1];
+    out->samples_pending = q;
+    return AZ_OK;
+}

@@ -11,8 +11,9 @@
 //   P  f32   prior                  (src/mcts.py:274-279)
 //   FC u32   index of first child; children are contiguous, in insertion order
 //   IN u32   action | n_child << 8 | flags << 16
-// A game's nodes are bump-allocated; re-rooting moves the root index and a new
-// game resets the allocator.  Noisy root priors (float64 in the reference after
+// Each game owns two arenas of `cap` nodes.  Nodes are bump-allocated in the
+// live arena; re-rooting (tree reuse) copies the kept subtree breadth-first into
+// the other arena and flips, so memory is bounded by the live tree.  Noisy root priors (float64 in the reference after
 // src/mcts.py:326) live in a per-game side array of 48 doubles.
 #include <vector>
 
@@ -33,6 +34,12 @@ __device__ inline void write_planes(float* dst, uint64_t mine, uint64_t theirs, 
         v.w = (float)((src >> (s0 + 3)) & 1ull);
         reinterpret_cast<float4*>(dst)[lane] = v;
     }
+}
+
+// game g's live arena (two arenas per game; re-rooting copies the kept subtree
+// into the other one)
+__device__ inline size_t pool_base(const EngineView& E, int g) {
+    return ((size_t)g * 2 + E.arena[g]) * E.cap;
 }
 
 __device__ inline double wave_max_f64(double v) {
@@ -65,7 +72,7 @@ __global__ __launch_bounds__(64) void k_roots_prepare(EngineView E, float* plane
         if (lane == 0) { E.leaf_need[g] = 0; if (need_eval) need_eval[g] = 0; }
         return;
     }
-    const size_t pool = (size_t)g * E.cap;
+    const size_t pool = pool_base(E, g);
     uint32_t r = E.root[g];
     const bool fresh = (r == NODE_NONE);
     if (fresh) {                        // Node(0): fresh tree, allocator reset
@@ -99,7 +106,7 @@ __global__ __launch_bounds__(64) void k_select(EngineView E, float* planes, uint
         if (lane == 0) { E.leaf_need[g] = 0; if (need_eval) need_eval[g] = 0; }
         return;
     }
-    const size_t pool = (size_t)g * E.cap;
+    const size_t pool = pool_base(E, g);
     const uint32_t r = E.root[g];
     const int rmode = E.root_mode[g];
     int t = E.turn[g];
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(64) void k_expand_backup(EngineView E, const float*
     __shared__ uint8_t s_a[MAX_CHILDREN];
     const int g = blockIdx.x, lane = threadIdx.x;
     if (!E.active[g]) return;
-    const size_t pool = (size_t)g * E.cap;
+    const size_t pool = pool_base(E, g);
     const int need = E.leaf_need[g];
     if (need) {
         const uint64_t mine = E.leaf_mine[g], theirs = E.leaf_theirs[g];
@@ -247,39 +254,6 @@ __global__ __launch_bounds__(64) void k_expand_backup(EngineView E, const float*
 }
 
 // ---------------------------------------------------------------------------
-// counter-based generator for the device-drawn Dirichlet noise and move sampling
-__device__ inline uint64_t mix64(uint64_t z) {
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-struct Rng {
-    uint64_t key, ctr;
-    __device__ Rng(uint64_t seed, uint64_t a, uint64_t b, uint64_t c)
-        : key(mix64(seed ^ mix64(a * 0x9E3779B97F4A7C15ull + b) ^ (c << 32))), ctr(0) {}
-    __device__ uint64_t next() { return mix64(key + 0x9E3779B97F4A7C15ull * (++ctr)); }
-    __device__ double uniform() { return ((double)(next() >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
-    __device__ double normal() {
-        const double u1 = uniform(), u2 = uniform();
-        return sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
-    }
-    // Marsaglia-Tsang, boosted for shape < 1
-    __device__ double gamma(double a) {
-        const double boost = (a < 1.0) ? pow(uniform(), 1.0 / a) : 1.0;
-        const double aa = (a < 1.0) ? a + 1.0 : a;
-        const double d = aa - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
-        for (int it = 0; it < 64; ++it) {
-            const double x = normal();
-            double v = 1.0 + c * x;
-            if (v <= 0) continue;
-            v = v * v * v;
-            const double u = uniform();
-            if (log(u) < 0.5 * x * x + d - d * v + d * log(v)) return d * v * boost;
-        }
-        return d * boost;
-    }
-};
-
 // _add_dirichlet_noise (src/mcts.py:314-326)
 __global__ __launch_bounds__(64) void k_add_noise(EngineView E, const double* noise,
                                                   uint64_t call_id) {
@@ -287,7 +261,7 @@ __global__ __launch_bounds__(64) void k_add_noise(EngineView E, const double* no
     if (!E.active[g]) return;
     const uint32_t r = E.root[g];
     if (r == NODE_NONE) return;
-    const size_t pool = (size_t)g * E.cap;
+    const size_t pool = pool_base(E, g);
     const uint32_t inf = E.IN[pool + r];
     const int k = (inf >> 8) & 0xFF;
     if (k == 0) return;
@@ -325,7 +299,7 @@ __global__ __launch_bounds__(64) void k_action_probs(EngineView E, const float* 
     __shared__ float row[192];
     const int g = blockIdx.x, lane = threadIdx.x;
     if (!E.active[g]) return;
-    const size_t pool = (size_t)g * E.cap;
+    const size_t pool = pool_base(E, g);
     const uint32_t r = E.root[g];
     int k = 0; uint32_t fc = 0;
     if (r != NODE_NONE) { k = (E.IN[pool + r] >> 8) & 0xFF; fc = E.FC[pool + r]; }
@@ -353,12 +327,54 @@ __global__ __launch_bounds__(64) void k_action_probs(EngineView E, const float* 
 }
 
 // ---------------------------------------------------------------------------
+// Re-root game g at node `src` of its live arena: breadth-first copy of that
+// subtree into the other arena (children stay contiguous and in insertion
+// order, N/W/P bit patterns unchanged), then flip arenas.  One wave.
+__device__ void reroot_subtree(EngineView E, int g, uint32_t src, int lane) {
+    const size_t from = pool_base(E, g);
+    const size_t to = ((size_t)g * 2 + (E.arena[g] ^ 1)) * E.cap;
+    if (lane == 0) {
+        E.N[to] = E.N[from + src]; E.W[to] = E.W[from + src]; E.P[to] = E.P[from + src];
+        E.FC[to] = E.FC[from + src]; E.IN[to] = E.IN[from + src];
+    }
+    __syncthreads();
+    uint32_t count = 1, head = 0;
+    while (head < count) {
+        const uint32_t nb = min(64u, count - head);
+        uint32_t k = 0, old_fc = 0;
+        if ((uint32_t)lane < nb) {
+            k = (E.IN[to + head + lane] >> 8) & 0xFF;
+            old_fc = E.FC[to + head + lane];
+        }
+        uint32_t incl = k;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        const uint32_t total = __shfl(incl, 63);
+        const uint32_t off = count + incl - k;
+        if ((uint32_t)lane < nb && k > 0) E.FC[to + head + lane] = off;
+        for (uint32_t j = 0; j < nb; ++j) {
+            const uint32_t kj = __shfl(k, (int)j), oj = __shfl(old_fc, (int)j), dj = __shfl(off, (int)j);
+            if ((uint32_t)lane < kj) {
+                const size_t a = from + oj + lane, d = to + dj + lane;
+                E.N[d] = E.N[a]; E.W[d] = E.W[a]; E.P[d] = E.P[a]; E.FC[d] = E.FC[a]; E.IN[d] = E.IN[a];
+            }
+        }
+        __syncthreads();  // the copied nodes are read back as the next frontier
+        count += total;
+        head += nb;
+    }
+    if (lane == 0) { E.arena[g] ^= 1; E.root[g] = 0; E.used[g] = count; }
+}
+
 // game.step + tree reuse (src/parallel_trainer.py:190-198, src/game.py:156-187)
 __global__ __launch_bounds__(64) void k_advance(EngineView E, const int16_t* actions) {
     const int g = blockIdx.x, lane = threadIdx.x;
     const int a = actions[g];
     if (a < 0) return;
-    const size_t pool = (size_t)g * E.cap;
+    const size_t pool = pool_base(E, g);
     const uint32_t r = E.root[g];
     uint32_t newroot = NODE_NONE;
     if (r != NODE_NONE) {
@@ -369,9 +385,8 @@ __global__ __launch_bounds__(64) void k_advance(EngineView E, const int16_t* act
         if (m) newroot = fc + (__ffsll((long long)m) - 1);
     }
     if (lane == 0) {
-        E.root[g] = newroot;
         E.root_mode[g] = 0;
-        if (newroot == NODE_NONE) E.used[g] = 0;
+        if (newroot == NODE_NONE) { E.root[g] = NODE_NONE; E.used[g] = 0; }
         uint64_t w = E.white[g], b = E.black[g];
         const int t = E.turn[g];
         int win = E.winner[g];
@@ -384,6 +399,7 @@ __global__ __launch_bounds__(64) void k_advance(EngineView E, const int16_t* act
         E.white[g] = w; E.black[g] = b; E.turn[g] = (int8_t)(-t); E.winner[g] = (int8_t)win;
         E.ply[g] = E.ply[g] + 1;
     }
+    if (newroot != NODE_NONE) reroot_subtree(E, g, newroot, lane);
 }
 
 __global__ void k_set_positions(EngineView E, int n, const int32_t* slots, const uint64_t* w,
@@ -395,16 +411,17 @@ __global__ void k_set_positions(EngineView E, int n, const int32_t* slots, const
     E.root[g] = NODE_NONE; E.used[g] = 0; E.root_mode[g] = 0; E.ply[g] = 0; E.leaf_need[g] = 0;
 }
 
-__global__ void k_set_root(EngineView E, int g, int64_t node) {
-    if (node < 0) { E.root[g] = NODE_NONE; E.used[g] = 0; }
-    else E.root[g] = (uint32_t)node;
-    E.root_mode[g] = 0;
+__global__ __launch_bounds__(64) void k_set_root(EngineView E, int g, int64_t node) {
+    const int lane = threadIdx.x;
+    if (lane == 0) E.root_mode[g] = 0;
+    if (node < 0) { if (lane == 0) { E.root[g] = NODE_NONE; E.used[g] = 0; } return; }
+    reroot_subtree(E, g, (uint32_t)node, lane);
 }
 
 __global__ __launch_bounds__(64) void k_node_children(EngineView E, int g, int64_t node_in,
                                                       NodeQuery* out) {
     const int lane = threadIdx.x;
-    const size_t pool = (size_t)g * E.cap;
+    const size_t pool = pool_base(E, g);
     const uint32_t r = E.root[g];
     const uint32_t node = (node_in < 0) ? r : (uint32_t)node_in;
     if (node == NODE_NONE) { if (lane == 0) { out->k = -1; out->node_index = -1; } return; }
@@ -450,8 +467,18 @@ static int engine_alloc(az_engine* e) {
     AZ_ALLOC(V.leaf_node, B); AZ_ALLOC(V.leaf_mine, B); AZ_ALLOC(V.leaf_theirs, B);
     AZ_ALLOC(V.leaf_turn, B); AZ_ALLOC(V.leaf_need, B); AZ_ALLOC(V.leaf_tv, B);
     AZ_ALLOC(V.path_len, B); AZ_ALLOC(V.path, B * MAX_DEPTH);
-    AZ_ALLOC(V.N, B * cap); AZ_ALLOC(V.W, B * cap); AZ_ALLOC(V.P, B * cap);
-    AZ_ALLOC(V.FC, B * cap); AZ_ALLOC(V.IN, B * cap);
+    AZ_ALLOC(V.arena, B);
+#define AZ_ALLOC_RAW(ptr, count)                                                      \
+    do {                                                                              \
+        void* _p = nullptr;                                                           \
+        AZ_HIP(hipMalloc(&_p, (count) * sizeof(*(ptr))));                             \
+        (ptr) = (decltype(ptr))_p;                                                    \
+        e->allocs.push_back(_p);                                                      \
+    } while (0)
+    // node pool: two arenas per game; nodes are initialised when allocated
+    AZ_ALLOC_RAW(V.N, 2 * B * cap); AZ_ALLOC_RAW(V.W, 2 * B * cap); AZ_ALLOC_RAW(V.P, 2 * B * cap);
+    AZ_ALLOC_RAW(V.FC, 2 * B * cap); AZ_ALLOC_RAW(V.IN, 2 * B * cap);
+#undef AZ_ALLOC_RAW
     AZ_ALLOC(V.err, 1); AZ_ALLOC(V.stat_depth, 1); AZ_ALLOC(V.stat_descents, 1);
     AZ_ALLOC(e->stage_slots, B); AZ_ALLOC(e->stage_w, B); AZ_ALLOC(e->stage_b, B);
     AZ_ALLOC(e->stage_t, B); AZ_ALLOC(e->stage_win, B); AZ_ALLOC(e->stage_act, B);
@@ -478,7 +505,7 @@ extern "C" int az_engine_create(az_engine** out, const az_engine_config* cfg) {
     V.temp_thr = cfg->temperature_threshold;
     V.seed = cfg->seed;
     int64_t cap = cfg->pool_nodes_per_game;
-    if (cap <= 0) cap = 1 << 20;
+    if (cap <= 0) cap = 1 << 18;
     AZ_CHECK_ARG(cap >= 64 && cap < (1ll << 31), "az_engine_create: pool_nodes_per_game out of range");
     V.cap = (uint32_t)cap;
     const int rc = engine_alloc(e);
@@ -655,16 +682,22 @@ extern "C" int az_engine_advance(az_engine* e, const int16_t* actions_host, void
         AZ_CHECK_ARG(actions_host[i] < 192, "az_engine_advance: action %d out of range", actions_host[i]);
     hipStream_t s = (hipStream_t)stream;
     AZ_HIP(hipMemcpyAsync(e->stage_act, actions_host, e->v.B * sizeof(int16_t), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_advance, dim3(e->v.B), dim3(64), 0, s, e->v, e->stage_act);
-    AZ_HIP(hipGetLastError());
+    const int rc = az::advance_dev(e, e->stage_act, s);
+    if (rc != AZ_OK) return rc;
     AZ_HIP(hipStreamSynchronize(s));
+    return AZ_OK;
+}
+
+int az::advance_dev(az_engine* e, const int16_t* actions_dev, hipStream_t s) {
+    hipLaunchKernelGGL(k_advance, dim3(e->v.B), dim3(64), 0, s, e->v, actions_dev);
+    AZ_HIP(hipGetLastError());
     return AZ_OK;
 }
 
 extern "C" int az_engine_set_root(az_engine* e, int32_t g, int64_t node, void* stream) {
     AZ_CHECK_ARG(e && g >= 0 && g < e->v.B, "az_engine_set_root: game %d out of range", g);
     AZ_CHECK_ARG(node < (int64_t)e->v.cap, "az_engine_set_root: node out of range");
-    hipLaunchKernelGGL(k_set_root, dim3(1), dim3(1), 0, (hipStream_t)stream, e->v, g, node);
+    hipLaunchKernelGGL(k_set_root, dim3(1), dim3(64), 0, (hipStream_t)stream, e->v, g, node);
     AZ_HIP(hipGetLastError());
     return AZ_OK;
 }

@@ -185,3 +185,46 @@ class Engine:
             self.select()
             probs, values = evaluate(self.planes, self.need)
             self.expand_backup(probs, values)
+
+    # ------------------------------------------------------------ fused self-play
+    def attach_net(self, inference):
+        """inference: alphazero_amd.model.HipInference with max_batch >= n_games."""
+        check(_lib.lib().az_engine_attach_net(self.h, inference.h))
+        self.net = inference
+
+    def search(self, num_simulations, add_noise=False):
+        check(_lib.lib().az_engine_search(self.h, int(num_simulations), int(bool(add_noise)), _stream()))
+
+    def play_move(self, num_simulations, add_noise=True, actions=None, restart_finished=True):
+        a = None if actions is None else np.ascontiguousarray(actions, np.int16)
+        check(_lib.lib().az_engine_play_move(self.h, int(num_simulations), int(bool(add_noise)),
+                                             _host_ptr(a), int(bool(restart_finished)), _stream()))
+
+    def chosen_actions(self):
+        a = np.zeros(self.n, np.int16)
+        check(_lib.lib().az_engine_chosen_actions(self.h, _host_ptr(a), _stream()))
+        return a
+
+    def samples_pending(self):
+        n = C.c_int64()
+        check(_lib.lib().az_engine_drain_samples(self.h, 0, None, None, None, C.byref(n), _stream()))
+        return n.value
+
+    def drain_samples(self):
+        """-> (states[n,3,8,8], policies[n,192], wls[n,2]) float32 cuda tensors."""
+        n = self.samples_pending()
+        states = torch.empty((n, 3, 8, 8), dtype=torch.float32, device=self.device)
+        policies = torch.empty((n, 192), dtype=torch.float32, device=self.device)
+        wls = torch.empty((n, 2), dtype=torch.float32, device=self.device)
+        if n:
+            got = C.c_int64()
+            check(_lib.lib().az_engine_drain_samples(self.h, n, _dev_ptr(states), _dev_ptr(policies),
+                                                     _dev_ptr(wls), C.byref(got), _stream()))
+            assert got.value == n
+        return states, policies, wls
+
+    def stats(self):
+        st = _lib.SelfplayStats()
+        check(_lib.lib().az_engine_selfplay_stats(self.h, C.byref(st), _stream()))
+        return dict(simulations=st.simulations, nn_evals=st.nn_evals, moves=st.moves,
+                    games_finished=st.games_finished, samples_pending=st.samples_pending)

@@ -69,6 +69,7 @@ typedef struct {
 
 int az_net_create(az_net** out, const az_net_config* cfg);
 int az_net_destroy(az_net* n);
+int az_net_max_batch(az_net* n);
 /* state_host: every floating-point tensor of AlphaZeroNet.state_dict()
  * (src/model.py:123-142), flattened and concatenated in state_dict order
  * (num_batches_tracked entries skipped), float32, `count` floats in total.
@@ -169,6 +170,40 @@ int az_engine_pool_usage(az_engine* e, uint32_t* used_host, void* stream);
 /* Sum of selection path lengths (nodes below the root) and number of descents
  * since creation: mean depth = depth_sum / descents. */
 int az_engine_stats(az_engine* e, uint64_t* depth_sum_host, uint64_t* descents_host, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Fused self-play: the whole of ParallelTrainer.execute_parallel_episodes
+ * (src/parallel_trainer.py:137-223) on the device, evaluating leaves with an
+ * attached az_net (whose max_batch must be >= n_games).
+ */
+typedef struct {
+    uint64_t simulations;     /* descents backed up since creation */
+    uint64_t nn_evals;        /* leaves + roots sent to the network */
+    uint64_t moves;           /* plies played */
+    uint64_t games_finished;
+    uint64_t samples_pending; /* finished-game samples waiting in the queue */
+} az_selfplay_stats;
+
+int az_engine_attach_net(az_engine* e, az_net* n);
+/* One MCTS.search_batch call (src/mcts.py:94-189): expand missing roots,
+ * optional device-drawn Dirichlet noise, num_simulations simulations. */
+int az_engine_search(az_engine* e, int32_t num_simulations, int32_t add_noise, void* stream);
+/* One iteration of the self-play loop (src/parallel_trainer.py:158-217) for
+ * every active game: search, visit-count policy with the temperature schedule,
+ * record (state, pi, turn), choose the move (actions_host[g] if given, else a
+ * device draw from pi), step + re-root, and for finished games emit their
+ * samples into the queue and restart them (restart_finished != 0) or drop them
+ * from the active set. */
+int az_engine_play_move(az_engine* e, int32_t num_simulations, int32_t add_noise,
+                        const int16_t* actions_host, int32_t restart_finished, void* stream);
+int az_engine_chosen_actions(az_engine* e, int16_t* actions_host, void* stream);
+/* Move the queued samples into the caller's device buffers in the layout of
+ * src/parallel_trainer.py:380-382 (states [n][3][8][8], policies [n][192],
+ * wls [n][2], float32) and empty the queue; *n_out = samples written.  With
+ * states_dev == NULL only the count is reported. */
+int az_engine_drain_samples(az_engine* e, int64_t max_samples, float* states_dev,
+                            float* policies_dev, float* wls_dev, int64_t* n_out, void* stream);
+int az_engine_selfplay_stats(az_engine* e, az_selfplay_stats* out, void* stream);
 
 #ifdef __cplusplus
 }

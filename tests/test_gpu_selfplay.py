@@ -1,0 +1,96 @@
+"""GPU: the fused self-play loop (search with the HIP network, device move
+choice, tree reuse, sample queue)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def small_model():
+    from alphazero_amd.model import AlphaZeroNet
+    torch.manual_seed(5)
+    return AlphaZeroNet(num_blocks=2, num_filters=128).eval()
+
+
+def test_fused_search_equals_stepwise_search(small_model):
+    """az_engine_search (network inside the library) must build exactly the tree
+    that the step API builds when fed the same network's outputs."""
+    from alphazero_amd.engine import Engine
+    from alphazero_amd.model import HipInference
+    nG, S = 32, 64
+    inf = HipInference(small_model, max_batch=64)
+    w, b, t, win = orc.random_positions(600, seed=9)
+    idx = [i for i in range(600) if win[i] == 0][:: 600 // nG][:nG]
+    fused, step = Engine(nG, pool_nodes_per_game=1 << 15), Engine(nG, pool_nodes_per_game=1 << 15)
+    for e in (fused, step):
+        e.set_positions(np.arange(nG), w[idx], b[idx], t[idx])
+    fused.attach_net(inf)
+    fused.search(S, add_noise=False)
+
+    def evaluate(planes, need):
+        probs, value, _, _ = inf.forward_planes(planes)
+        return probs, value
+    step.search_with(evaluate, S)
+    for g in range(nG):
+        a, o = fused.root_children(g), step.root_children(g)
+        assert np.array_equal(a["actions"], o["actions"])
+        assert np.array_equal(a["N"], o["N"])
+        assert np.array_equal(a["W"].view(np.uint32), o["W"].view(np.uint32))
+        assert a["root_N"] == S
+
+
+def test_selfplay_games_are_legal_and_samples_consistent(small_model):
+    from alphazero_amd.selfplay import SelfPlay
+    nG, S = 16, 24
+    sp = SelfPlay(small_model, n_games=nG, num_simulations=S, seed=3, pool_nodes_per_game=1 << 15)
+    e = sp.engine
+    e.reset_all()
+    pos = [orc.start_position() for _ in range(nG)]
+    plies = np.zeros(nG, int)
+    finished = 0
+    states, policies, wls = [], [], []
+    for it in range(400):
+        w0, b0, t0, _ = e.get_positions()
+        e.play_move(S, add_noise=True, restart_finished=False)
+        acts = e.chosen_actions()
+        w1, b1, t1, win1 = e.get_positions()
+        for g in range(nG):
+            if acts[g] < 0:
+                continue
+            assert acts[g] in orc.legal_actions(pos[g]), "engine played an illegal move"
+            pos[g] = orc.step_action(pos[g], int(acts[g]))
+            plies[g] += 1
+            assert (pos[g].white, pos[g].black, pos[g].turn, pos[g].winner) == (int(w1[g]), int(b1[g]), int(t1[g]), int(win1[g]))
+        st = e.stats()
+        if st["games_finished"] == nG:
+            break
+    assert e.stats()["games_finished"] == nG
+    s, p, wl = [x.cpu().numpy() for x in e.drain_samples()]
+    assert len(s) == plies.sum() == e.stats()["moves"]
+    assert np.allclose(p.sum(1), 1.0, atol=1e-5)
+    assert set(np.unique(s)) <= {0.0, 1.0} and np.all(s[:, 2] == 1.0)
+    assert np.all(wl.sum(1) == 1.0)
+    # every game is decisive: per game the winners' and losers' plies alternate
+    for g in range(nG):
+        assert orc.is_terminal(pos[g])
+    # after ply 16 the policy is one-hot (temperature 0)
+    onehot = (p.max(1) == 1.0).sum()
+    assert onehot >= (plies - 16).clip(0).sum()
+
+
+def test_continuous_selfplay_restarts_and_drains(small_model):
+    from alphazero_amd.selfplay import SelfPlay
+    sp = SelfPlay(small_model, n_games=8, num_simulations=8, seed=1, pool_nodes_per_game=1 << 14)
+    for _ in range(150):
+        sp.step(restart_finished=True)
+    st = sp.engine.stats()
+    assert st["moves"] == 150 * 8
+    assert st["games_finished"] >= 8
+    s, p, wl = sp.engine.drain_samples()
+    assert len(s) == st["samples_pending"] > 0
+    assert sp.engine.stats()["samples_pending"] == 0
+    assert st["simulations"] == 150 * 8 * 8
