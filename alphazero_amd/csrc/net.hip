@@ -505,7 +505,13 @@ struct az_net {
     float *part_p = nullptr, *part_v = nullptr;
     uint64_t *bits_mine = nullptr, *bits_theirs = nullptr;
     int32_t* bad = nullptr;
+    // optional HIP-event timing of the tower kernel (az_net_set_timing)
+    bool timing = false;
+    int64_t launches = 0;
+    int ev_used = 0;
+    std::vector<hipEvent_t> ev0, ev1;
 };
+constexpr int TIMING_POOL = 512, TIMING_STRIDE = 8;
 
 static uint16_t f32_to_bf16(float f) {
     uint32_t u;
@@ -526,8 +532,37 @@ static int dev_alloc(az_net* n, T*& ptr, size_t count) {
 
 extern "C" int az_net_max_batch(az_net* n) { return n ? n->max_batch : 0; }
 
+extern "C" int az_net_set_timing(az_net* n, int32_t enable) {
+    AZ_CHECK_ARG(n, "az_net_set_timing: null network");
+    if (enable && n->ev0.empty()) {
+        n->ev0.resize(TIMING_POOL); n->ev1.resize(TIMING_POOL);
+        for (int i = 0; i < TIMING_POOL; ++i) { AZ_HIP(hipEventCreate(&n->ev0[i])); AZ_HIP(hipEventCreate(&n->ev1[i])); }
+    }
+    n->timing = enable != 0;
+    n->ev_used = 0;
+    n->launches = 0;
+    return AZ_OK;
+}
+
+extern "C" int az_net_tower_time(az_net* n, double* mean_ms, int64_t* samples) {
+    AZ_CHECK_ARG(n && mean_ms && samples, "az_net_tower_time: null argument");
+    double sum = 0;
+    for (int i = 0; i < n->ev_used; ++i) {
+        AZ_HIP(hipEventSynchronize(n->ev1[i]));
+        float ms = 0;
+        AZ_HIP(hipEventElapsedTime(&ms, n->ev0[i], n->ev1[i]));
+        sum += ms;
+    }
+    *samples = n->ev_used;
+    *mean_ms = n->ev_used ? sum / n->ev_used : 0.0;
+    n->ev_used = 0;
+    return AZ_OK;
+}
+
 extern "C" int az_net_destroy(az_net* n) {
     if (!n) return AZ_OK;
+    for (hipEvent_t ev : n->ev0) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : n->ev1) (void)hipEventDestroy(ev);
     for (void* p : n->allocs) (void)hipFree(p);
     delete n;
     return AZ_OK;
@@ -724,7 +759,10 @@ extern "C" int az_net_forward(az_net* n, int32_t B, const uint64_t* mine_dev, co
     tp.stem_w = n->stem_w; tp.stem_b = n->stem_b; tp.conv_w = n->conv_w; tp.conv_b = n->conv_b;
     tp.se_w1 = n->se_w1; tp.se_b1 = n->se_b1; tp.se_w2 = n->se_w2; tp.se_b2 = n->se_b2;
     tp.value_w = n->value_w; tp.value_b = n->value_b; tp.p_act = n->p_act; tp.v_act = n->v_act;
+    const bool stamp = n->timing && (n->launches++ % TIMING_STRIDE == 0) && n->ev_used < TIMING_POOL;
+    if (stamp) AZ_HIP(hipEventRecord(n->ev0[n->ev_used], s));
     hipLaunchKernelGGL(k_tower, dim3((B + 3) / 4), dim3(256), 0, s, tp);
+    if (stamp) AZ_HIP(hipEventRecord(n->ev1[n->ev_used++], s));
     HeadParams hp{n->p_act, n->v_act, n->wp, n->wv, n->part_p, n->part_v, B};
     hipLaunchKernelGGL(k_head_gemm, dim3((B + 15) / 16, POLICY_CHUNKS + VALUE_CHUNKS), dim3(256), 0, s, hp);
     FinishParams fp{n->part_p, n->part_v, n->bp, n->bv1, n->wv2, n->bv2, probs_dev, value_dev,

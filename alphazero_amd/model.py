@@ -130,6 +130,15 @@ class HipInference:
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().az_net_load_state(self.h, C.c_void_p(blob.data_ptr()), blob.numel()))
 
+    def set_timing(self, enable=True):
+        _lib.check(_lib.lib().az_net_set_timing(self.h, int(bool(enable))))
+
+    def tower_time(self):
+        """-> (mean milliseconds per tower-kernel launch, samples) since the last call."""
+        ms, n = C.c_double(), C.c_int64()
+        _lib.check(_lib.lib().az_net_tower_time(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def close(self):
         if getattr(self, "h", None):
             _lib.lib().az_net_destroy(self.h)

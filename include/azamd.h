@@ -90,6 +90,13 @@ int az_net_forward_planes(az_net* n, int32_t B, const float* planes_dev, float* 
                           float* value_dev, float* policy_logits_dev, float* wl_logits_dev,
                           void* stream);
 
+/* Measurement aid (no reference counterpart): with timing enabled, every 8th
+ * tower-kernel launch is bracketed by HIP events on the stream it runs on (up
+ * to 512 samples); az_net_tower_time waits for them, returns their mean
+ * duration in milliseconds and the sample count, and clears the pool. */
+int az_net_set_timing(az_net* n, int32_t enable);
+int az_net_tower_time(az_net* n, double* mean_ms, int64_t* samples);
+
 /* ------------------------------------------------------------------------
  * Search engine: B independent games, one tree each, nodes in an SoA pool in
  * HBM, one wavefront per game.  Replaces MCTS.search_batch and its helpers
