@@ -24,6 +24,7 @@
 // BatchNorm (eval mode, eps 1e-5) is folded into the conv weights and a bias at
 // load time.  Arithmetic: bf16 operands, float32 accumulation, float32 epilogues.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -42,7 +43,18 @@ constexpr int ACT_REGION = 64 * ACT_PITCH;     // 17408 B per position
 constexpr int LDS_ZERO = 4 * ACT_REGION;       // 69632: a zeroed pixel row for out-of-board taps
 constexpr int LDS_W = LDS_ZERO + 512;          // 70144: two 32 KB weight buffers
 constexpr int TAP_BYTES = 8 * 4 * 64 * 16;     // 32768: [ks 8][nt 4][lane 64][16 B]
-constexpr int LDS_TOTAL = LDS_W + 2 * TAP_BYTES;  // 135680
+constexpr int LDS_BIAS = LDS_W + 2 * TAP_BYTES;   // 135680: folded-BN bias of the running conv, 2 x 512 B
+constexpr int LDS_SE = LDS_BIAS + 1024;           // 136704: squeeze-excitation weights of the running block
+// SE image (float32): W1 [16][132] (row pitch padded for conflict-free b128 reads),
+// b1 [16], W2 transposed [16][256], b2 [256]; padded to a whole number of 1 KB DMA pieces
+constexpr int SE_W1_PITCH = 132;
+constexpr int SE_OFF_B1 = 16 * SE_W1_PITCH;            // floats
+constexpr int SE_OFF_W2 = SE_OFF_B1 + 16;
+constexpr int SE_OFF_B2 = SE_OFF_W2 + 16 * 256;
+constexpr int SE_FLOATS = SE_OFF_B2 + 256;             // 6480 floats = 25920 B
+constexpr int SE_PIECES = (SE_FLOATS * 4 + 1023) / 1024;  // 26
+constexpr int SE_BYTES = SE_PIECES * 1024;             // 26624
+constexpr int LDS_TOTAL = LDS_SE + SE_BYTES;           // 163328 <= 163840
 constexpr int CONV_BYTES = 9 * TAP_BYTES;      // 294912
 constexpr int VALUE_CH = 32;
 constexpr int SE_HID = 16;
@@ -61,14 +73,12 @@ struct TowerParams {
     const float* stem_b;        // [128]
     const uint8_t* conv_w;      // [2*blocks+1][CONV_BYTES]; the last one is the policy conv
     const float* conv_b;        // [2*blocks+1][128]
-    const float* se_w1;         // [blocks][16][128]
-    const float* se_b1;         // [blocks][16]
-    const float* se_w2;         // [blocks][256][16]
-    const float* se_b2;         // [blocks][256]
+    const uint8_t* se_img;      // [blocks][SE_BYTES] squeeze-excitation weights in their LDS image layout
     const uint8_t* value_w;     // [ks 8][lane 64][16 B]
     const float* value_b;       // [32]
     __bf16* p_act;              // [B][64 px][128 ch]
     __bf16* v_act;              // [B][64 px][32 ch]
+    int dbg;                    // diagnostic ablation flags (AZ_TOWER_DBG), 0 in production
 };
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
@@ -89,9 +99,54 @@ __device__ __forceinline__ bf16x8 lds_read_frag(const char* lds, uint32_t off) {
     return *reinterpret_cast<const bf16x8*>(lds + off);
 }
 
+// LDS-DMA copy of 64 x 16 B: global (per-lane address) -> LDS (wave-uniform base +
+// lane * 16).  Issued from inline asm so that the compiler's wait-count pass does not
+// see a FLAT instruction touching LDS (it would then drain lgkmcnt to 0 before every
+// MFMA group); the matching s_waitcnt vmcnt(0) is placed by hand before the barrier
+// that publishes the buffer (wait_weights()).
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+// same, 64 x 4 B
+__device__ __forceinline__ void glds4(const void* gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+__device__ __forceinline__ void wait_weights() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+struct Frags {
+    bf16x8 x[2];  // activation fragments of the two pixel tiles
+    bf16x8 w[4];  // weight fragments of the four channel tiles
+};
+
+__device__ __forceinline__ void load_frags(Frags& f, const char* lds, uint32_t a0, uint32_t a1,
+                                           uint32_t wb, int ks) {
+    f.x[0] = lds_read_frag(lds, a0 + ks * 32);
+    f.x[1] = lds_read_frag(lds, a1 + ks * 32);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) f.w[nt] = lds_read_frag(lds, wb + (ks * 4 + nt) * 1024);
+}
+
+__device__ __forceinline__ void mma_step(f32x16 (&acc)[4][2], const Frags& f) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w[nt], f.x[0], acc[nt][0], 0, 0, 0);
+        acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w[nt], f.x[1], acc[nt][1], 0, 0, 0);
+    }
+}
+
 // acc[nt][pt][v] + bias -> optional ReLU -> bf16 -> the wave's LDS region, and
 // (optionally) the packed copy kept in registers as the next residual.
-template <bool RELU, bool KEEP>
+template <bool RELU, bool KEEP, bool BIAS>
 __device__ __forceinline__ void store_act(char* region, const f32x16 (&acc)[4][2],
                                           const float* bias, uint32_t (&keep)[4][2][8], int r,
                                           int h) {
@@ -100,7 +155,8 @@ __device__ __forceinline__ void store_act(char* region, const f32x16 (&acc)[4][2
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             const int ch0 = nt * 32 + gq * 8 + h * 4;
-            const f32x4 b = *reinterpret_cast<const f32x4*>(bias + ch0);
+            f32x4 b = {0.f, 0.f, 0.f, 0.f};
+            if (BIAS) b = *reinterpret_cast<const f32x4*>(bias + ch0);
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt) {
                 float v0 = acc[nt][pt][gq * 4 + 0] + b[0];
@@ -114,6 +170,7 @@ __device__ __forceinline__ void store_act(char* region, const f32x16 (&acc)[4][2
                 if (KEEP) { keep[nt][pt][gq * 2 + 0] = lo; keep[nt][pt][gq * 2 + 1] = hi; }
                 *reinterpret_cast<uint2*>(region + (pt * 32 + r) * ACT_PITCH + ch0 * 2) = make_uint2(lo, hi);
             }
+            __builtin_amdgcn_sched_barrier(0);  // keep the groups apart: hoisting all reads up front spills
         }
     }
 }
@@ -125,7 +182,7 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
     const int r = lane & 31, h = lane >> 5;
     const int pos = blockIdx.x * 4 + wave;
     const bool live = pos < p.B;
-    char* region = lds + wave * ACT_REGION;
+    char* region0 = lds + wave * ACT_REGION;
     const int nconv = 2 * p.blocks + 1;
     const int total_taps = nconv * 9;
 
@@ -133,12 +190,25 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
     for (int i = tid; i < 512 / 4; i += 256) reinterpret_cast<uint32_t*>(lds + LDS_ZERO)[i] = 0;
 
     // weight stream: tap T of the conv sequence -> buffer T&1; each wave copies 8 KB
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_void*)lds;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     auto prefetch = [&](int T) {
-        const uint8_t* src = p.conv_w + (size_t)T * TAP_BYTES + wave * 8192 + lane * 16;
-        char* dst = lds + LDS_W + (T & 1) * TAP_BYTES + wave * 8192;
+        const uint8_t* src = p.conv_w + (size_t)T * TAP_BYTES + wave_u * 8192 + lane * 16;
+        const uint32_t dst = lds_base + LDS_W + (T & 1) * TAP_BYTES + wave_u * 8192;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            __builtin_amdgcn_global_load_lds((const void*)(src + i * 1024), (lds_void*)(dst + i * 1024), 16, 0, 0);
+        for (int i = 0; i < 8; ++i) glds16(src + i * 1024, __builtin_amdgcn_readfirstlane(dst + i * 1024));
+    };
+    // folded-BN bias of conv c -> LDS bias buffer c&1 (waves 0 and 1, 256 B each)
+    auto prefetch_bias = [&](int c) {
+        if (wave_u < 2)
+            glds4(reinterpret_cast<const uint8_t*>(p.conv_b + (size_t)c * CH) + wave_u * 256 + lane * 4,
+                  __builtin_amdgcn_readfirstlane(lds_base + LDS_BIAS + (c & 1) * 512 + wave_u * 256));
+    };
+    // squeeze-excitation weights of block blk -> LDS, piece `piece` (1 KB) of SE_PIECES
+    auto prefetch_se = [&](int blk, int piece) {
+        if (piece < SE_PIECES)
+            glds16(p.se_img + (size_t)blk * SE_BYTES + piece * 1024 + lane * 16,
+                   __builtin_amdgcn_readfirstlane(lds_base + LDS_SE + piece * 1024));
     };
     prefetch(0);
 
@@ -193,9 +263,10 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
                 acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, xb[1], acc[nt][1], 0, 0, 0);
             }
         }
-        store_act<true, true>(region, acc, p.stem_b, resid, r, h);
+        store_act<true, true, true>(region0, acc, p.stem_b, resid, r, h);
     }
-    __syncthreads();  // tap 0 landed (the compiler drains vmcnt here), zero row visible
+    wait_weights();
+    __syncthreads();  // tap 0 landed, zero row visible
 
     for (int conv = 0; conv < nconv; ++conv) {
 #pragma unroll
@@ -204,28 +275,49 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
             for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[nt][pt][v] = 0.f;
+        // Software pipeline: the fragments of k-step s+1 are read from LDS while the
+        // 8 MFMAs of k-step s run.  The workgroup barrier of a tap sits between its
+        // k-steps 6 and 7 (k-step 7's fragments are in registers by then), so the
+        // first fragments of the next tap are read behind it, under k-step 7's MFMAs.
+        Frags f0, f1;
+        load_frags(f0, lds, aaddr[0][0], aaddr[0][1], LDS_W + ((conv * 9) & 1) * TAP_BYTES + lane * 16, 0);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int T = conv * 9 + tap;
             if (T + 1 < total_taps) prefetch(T + 1);
+            if (tap == 0) prefetch_bias(conv);
+            if ((conv & 1) && tap < 7 && conv < nconv - 1) prefetch_se(conv >> 1, tap * 4 + wave_u);
             const uint32_t wb = LDS_W + (T & 1) * TAP_BYTES + lane * 16;
+            const uint32_t wb_next = LDS_W + ((T + 1) & 1) * TAP_BYTES + lane * 16;
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const bf16x8 x0 = lds_read_frag(lds, aaddr[tap][0] + ks * 32);
-                const bf16x8 x1 = lds_read_frag(lds, aaddr[tap][1] + ks * 32);
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    const bf16x8 w = lds_read_frag(lds, wb + (ks * 4 + nt) * 1024);
-                    acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x0, acc[nt][0], 0, 0, 0);
-                    acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x1, acc[nt][1], 0, 0, 0);
+            for (int ks = 0; ks < 8; ks += 2) {
+                load_frags(f1, lds, aaddr[tap][0], aaddr[tap][1], wb, ks + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_step(acc, f0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks + 2 < 8) {
+                    load_frags(f0, lds, aaddr[tap][0], aaddr[tap][1], wb, ks + 2);
+                } else {
+                    wait_weights();
+                    __syncthreads();  // next tap landed; everyone is done reading this buffer
+                    if (tap + 1 < 9) load_frags(f0, lds, aaddr[tap + 1 < 9 ? tap + 1 : 0][0], aaddr[tap + 1 < 9 ? tap + 1 : 0][1], wb_next, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                mma_step(acc, f1);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __syncthreads();  // next tap landed; everyone is done with this buffer
         }
-        const float* bias = p.conv_b + conv * CH;
+        // Epilogue addresses are rebuilt from an opaque zero on every pass: left
+        // loop-invariant, the compiler hoists dozens of them out of the conv loop and
+        // spills them to scratch, and every reload then sits on the critical path.
+        uint32_t oz;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(oz));
+        char* lds_e = lds + oz;
+        char* region = lds_e + wave * ACT_REGION;
+        const float* bias = reinterpret_cast<const float*>(lds_e + LDS_BIAS + (conv & 1) * 512);
         if (conv == nconv - 1) {
             // ---- policy conv: + bias, ReLU -> LDS -> p_act (coalesced 16 B per lane)
-            store_act<true, false>(region, acc, bias, resid, r, h);
+            store_act<true, false, true>(region, acc, bias, resid, r, h);
             if (live) {
                 char* out = reinterpret_cast<char*>(p.p_act) + (size_t)pos * 64 * CH * 2;
 #pragma unroll
@@ -237,36 +329,48 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
             }
         } else if ((conv & 1) == 0) {
             // ---- conv1 of a block: + bias, ReLU -> LDS
-            store_act<true, false>(region, acc, bias, resid, r, h);
+            store_act<true, false, true>(region, acc, bias, resid, r, h);
         } else {
             // ---- conv2 of a block: + bias, SE, + residual, ReLU -> LDS and registers
-            const int blk = conv >> 1;
             float* scratch = reinterpret_cast<float*>(region);  // the region is free now
-            // z = acc + bias; channel sums over the 64 pixels
+            const float* se = reinterpret_cast<const float*>(lds_e + LDS_SE);
+            if (p.dbg & 1) {
+                store_act<true, true, true>(region, acc, bias, resid, r, h);
+                continue;
+            }
+            // Squeeze: per-channel mean of z = acc + bias over the 64 pixels.  Per channel
+            // tile the 16 per-lane partial sums are reduce-scattered over the 32 lanes of
+            // each half (16 shuffles per tile instead of 16 x 5); acc itself is left
+            // untouched, the bias enters through the mean and through the shift below.
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
+                f32x16 v = acc[nt][0] + acc[nt][1];  // a register vector: constant indices only
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const int ch0 = nt * 32 + gq * 8 + h * 4;
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(bias + ch0);
-                    f32x4 s;
+                for (int step = 0; step < 4; ++step) {
+                    const int half = 8 >> step, o = 16 >> step;
+                    const bool up = (r & o) != 0;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        acc[nt][0][gq * 4 + q] += b[q];
-                        acc[nt][1][gq * 4 + q] += b[q];
-                        float t = acc[nt][0][gq * 4 + q] + acc[nt][1][gq * 4 + q];
-#pragma unroll
-                        for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o);
-                        s[q] = t * (1.0f / 64.0f);
+                    for (int i = 0; i < half; ++i) {
+                        float a = v[i], b = v[i + half];
+                        // opaque copy: otherwise the two selects below are rewritten as a
+                        // dynamically indexed vector read (a 16-way v_cndmask chain each)
+                        asm("" : "+v"(a));
+                        const float send = up ? a : b;
+                        const float keepv = up ? b : a;
+                        v[i] = keepv + __shfl_xor(send, o);
                     }
-                    if (r == 0) *reinterpret_cast<f32x4*>(scratch + ch0) = s;  // means[128]
                 }
+                const float tot = v[0] + __shfl_xor(v[0], 1);
+                const int idx = r >> 1;  // accumulator register index this lane pair reduced
+                const int ch = nt * 32 + (idx >> 2) * 8 + h * 4 + (idx & 3);
+                if ((r & 1) == 0) scratch[ch] = tot * (1.0f / 64.0f) + bias[ch];
+                __builtin_amdgcn_sched_barrier(0);
             }
             wave_lds_sync();
             // fc1 (128 -> 16) + ReLU: lane = (j = lane&15, quarter = lane>>4)
             {
                 const int j = lane & 15, q4 = lane >> 4;
-                const float* w1 = p.se_w1 + ((size_t)blk * SE_HID + j) * CH + q4 * 32;
+                const float* w1 = se + j * SE_W1_PITCH + q4 * 32;
                 float y = 0.f;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -276,31 +380,33 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
                 }
                 y += __shfl_xor(y, 16);
                 y += __shfl_xor(y, 32);
-                y = fmaxf(y + p.se_b1[blk * SE_HID + j], 0.f);
+                y = fmaxf(y + se[SE_OFF_B1 + j], 0.f);
                 if (lane < 16) scratch[128 + lane] = y;  // hidden[16]
             }
             wave_lds_sync();
-            // fc2 (16 -> 256): lane computes outputs lane + 64*m
+            // fc2 (16 -> 256) from the transposed weights: this lane computes the gate
+            // and the shift of channels lane and lane + 64; shift absorbs bias * gate
             {
                 f32x4 hid[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) hid[i] = *reinterpret_cast<const f32x4*>(scratch + 128 + i * 4);
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const int o = lane + 64 * m;
-                    const float* w2 = p.se_w2 + ((size_t)blk * 2 * CH + o) * SE_HID;
-                    float s = p.se_b2[blk * 2 * CH + o];
+                for (int m = 0; m < 2; ++m) {
+                    const int c = lane + 64 * m;
+                    const float* w2c = se + SE_OFF_W2 + c;  // one base register, immediate offsets below
+                    float g = w2c[16 * 256], sh = w2c[16 * 256 + CH];  // b2 follows W2 in the image
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const f32x4 w = *reinterpret_cast<const f32x4*>(w2 + i * 4);
-                        s += w[0] * hid[i][0] + w[1] * hid[i][1] + w[2] * hid[i][2] + w[3] * hid[i][3];
+                    for (int jj = 0; jj < 16; ++jj) {
+                        g += w2c[jj * 256] * hid[jj >> 2][jj & 3];
+                        sh += w2c[jj * 256 + CH] * hid[jj >> 2][jj & 3];
                     }
-                    if (m < 2) s = 1.0f / (1.0f + __expf(-s));  // sigmoid gate for channels 0..127
-                    scratch[160 + o] = s;                        // gate[128], shift[128]
+                    g = 1.0f / (1.0f + __expf(-g));  // sigmoid
+                    scratch[160 + c] = g;
+                    scratch[160 + CH + c] = sh + bias[c] * g;
                 }
             }
             wave_lds_sync();
-            // out = relu(z * gate + shift + residual)
+            // out = relu(acc * gate + shift' + residual)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
 #pragma unroll
@@ -316,9 +422,10 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
                         acc[nt][pt][gq * 4 + 2] = acc[nt][pt][gq * 4 + 2] * gt[2] + sh[2] + bf16_lo(rhi);
                         acc[nt][pt][gq * 4 + 3] = acc[nt][pt][gq * 4 + 3] * gt[3] + sh[3] + bf16_hi(rhi);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            store_act<true, true>(region, acc, p.conv_b + (size_t)nconv * CH /* zeros */, resid, r, h);
+            store_act<true, true, false>(region, acc, nullptr, resid, r, h);
             if (conv == nconv - 2) {
                 // ---- value head conv 1x1 (128 -> 32) on the tower output, + bias, ReLU -> v_act
                 f32x16 va[2];
@@ -499,8 +606,8 @@ struct az_net {
     bool loaded = false;
     std::vector<void*> allocs;
     uint8_t *stem_w = nullptr, *conv_w = nullptr, *value_w = nullptr, *wp = nullptr, *wv = nullptr;
-    float *stem_b = nullptr, *conv_b = nullptr, *se_w1 = nullptr, *se_b1 = nullptr, *se_w2 = nullptr,
-          *se_b2 = nullptr, *value_b = nullptr, *bp = nullptr, *bv1 = nullptr, *wv2 = nullptr, *bv2 = nullptr;
+    uint8_t* se_img = nullptr;
+    float *stem_b = nullptr, *conv_b = nullptr, *value_b = nullptr, *bp = nullptr, *bv1 = nullptr, *wv2 = nullptr, *bv2 = nullptr;
     __bf16 *p_act = nullptr, *v_act = nullptr;
     float *part_p = nullptr, *part_v = nullptr;
     uint64_t *bits_mine = nullptr, *bits_theirs = nullptr;
@@ -585,7 +692,7 @@ extern "C" int az_net_create(az_net** out, const az_net_config* cfg) {
 #define A(ptr, cnt) if (rc == AZ_OK) rc = dev_alloc(n, n->ptr, (cnt))
     A(stem_w, 2 * 4 * 64 * 16); A(stem_b, CH);
     A(conv_w, nconv * CONV_BYTES); A(conv_b, (nconv + 1) * CH);  // + one zero row
-    A(se_w1, nb * SE_HID * CH); A(se_b1, nb * SE_HID); A(se_w2, nb * 2 * CH * SE_HID); A(se_b2, nb * 2 * CH);
+    A(se_img, nb * SE_BYTES);
     A(value_w, 8 * 64 * 16); A(value_b, VALUE_CH);
     A(wp, (size_t)(POLICY_K / 32) * 12 * 64 * 16); A(bp, NUM_ACTIONS);
     A(wv, (size_t)(VALUE_K / 32) * 8 * 64 * 16); A(bv1, 128); A(wv2, 256); A(bv2, 2);
@@ -665,7 +772,7 @@ extern "C" int az_net_load_state(az_net* n, const float* s, int64_t count) {
     // tower
     std::vector<uint16_t> convs((size_t)(2 * nb + 1) * CONV_BYTES / 2);
     std::vector<float> conv_b((size_t)(2 * nb + 2) * CH, 0.f);
-    std::vector<float> w1((size_t)nb * SE_HID * CH), b1((size_t)nb * SE_HID), w2((size_t)nb * 2 * CH * SE_HID), b2((size_t)nb * 2 * CH);
+    std::vector<uint8_t> se_img((size_t)nb * SE_BYTES, 0);
     for (int blk = 0; blk < nb; ++blk) {
         for (int half = 0; half < 2; ++half) {
             const float* w = take((int64_t)CH * CH * 9);
@@ -675,10 +782,19 @@ extern "C" int az_net_load_state(az_net* n, const float* s, int64_t count) {
             pack_conv3x3(w, f.scale, convs.data() + (size_t)ci * CONV_BYTES / 2);
             memcpy(&conv_b[(size_t)ci * CH], f.bias.data(), CH * sizeof(float));
         }
-        memcpy(&w1[(size_t)blk * SE_HID * CH], take(SE_HID * CH), SE_HID * CH * sizeof(float));
-        memcpy(&b1[(size_t)blk * SE_HID], take(SE_HID), SE_HID * sizeof(float));
-        memcpy(&w2[(size_t)blk * 2 * CH * SE_HID], take(2 * CH * SE_HID), 2 * CH * SE_HID * sizeof(float));
-        memcpy(&b2[(size_t)blk * 2 * CH], take(2 * CH), 2 * CH * sizeof(float));
+        {   // squeeze-excitation: fc1.weight [16][128], fc1.bias [16], fc2.weight [256][16], fc2.bias [256]
+            float* img = reinterpret_cast<float*>(se_img.data() + (size_t)blk * SE_BYTES);
+            const float* fw1 = take(SE_HID * CH);
+            const float* fb1 = take(SE_HID);
+            const float* fw2 = take(2 * CH * SE_HID);
+            const float* fb2 = take(2 * CH);
+            for (int j = 0; j < SE_HID; ++j)
+                for (int c = 0; c < CH; ++c) img[j * SE_W1_PITCH + c] = fw1[j * CH + c];
+            for (int j = 0; j < SE_HID; ++j) img[SE_OFF_B1 + j] = fb1[j];
+            for (int o = 0; o < 2 * CH; ++o)
+                for (int j = 0; j < SE_HID; ++j) img[SE_OFF_W2 + j * 256 + o] = fw2[o * SE_HID + j];
+            for (int o = 0; o < 2 * CH; ++o) img[SE_OFF_B2 + o] = fb2[o];
+        }
     }
     // policy head
     {
@@ -738,10 +854,7 @@ extern "C" int az_net_load_state(az_net* n, const float* s, int64_t count) {
     if (q - s != count) AZ_FAIL(AZ_ERR_ARG, "az_net_load_state: internal layout mismatch");
     if ((rc = upload((uint16_t*)n->conv_w, convs))) return rc;
     if ((rc = upload(n->conv_b, conv_b))) return rc;
-    if ((rc = upload(n->se_w1, w1))) return rc;
-    if ((rc = upload(n->se_b1, b1))) return rc;
-    if ((rc = upload(n->se_w2, w2))) return rc;
-    if ((rc = upload(n->se_b2, b2))) return rc;
+    if ((rc = upload(n->se_img, se_img))) return rc;
     n->loaded = true;
     return AZ_OK;
 }
@@ -757,8 +870,10 @@ extern "C" int az_net_forward(az_net* n, int32_t B, const uint64_t* mine_dev, co
     TowerParams tp;
     tp.mine = mine_dev; tp.theirs = theirs_dev; tp.B = B; tp.blocks = n->blocks;
     tp.stem_w = n->stem_w; tp.stem_b = n->stem_b; tp.conv_w = n->conv_w; tp.conv_b = n->conv_b;
-    tp.se_w1 = n->se_w1; tp.se_b1 = n->se_b1; tp.se_w2 = n->se_w2; tp.se_b2 = n->se_b2;
+    tp.se_img = n->se_img;
     tp.value_w = n->value_w; tp.value_b = n->value_b; tp.p_act = n->p_act; tp.v_act = n->v_act;
+    static const int dbg = getenv("AZ_TOWER_DBG") ? atoi(getenv("AZ_TOWER_DBG")) : 0;
+    tp.dbg = dbg;
     const bool stamp = n->timing && (n->launches++ % TIMING_STRIDE == 0) && n->ev_used < TIMING_POOL;
     if (stamp) AZ_HIP(hipEventRecord(n->ev0[n->ev_used], s));
     hipLaunchKernelGGL(k_tower, dim3((B + 3) / 4), dim3(256), 0, s, tp);
