@@ -55,6 +55,8 @@ _SIGNATURES = {
     "az_engine_create": [C.POINTER(_VP), C.POINTER(EngineConfig)],
     "az_engine_destroy": [_VP],
     "az_engine_set_positions": [_VP, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP],
+    "az_engine_update_positions": [_VP, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP],
+    "az_engine_root_counts": [_VP, _VP, _VP],
     "az_engine_get_positions": [_VP, _VP, _VP, _VP, _VP, _VP],
     "az_engine_set_active": [_VP, _VP, _VP],
     "az_engine_roots_prepare": [_VP, _VP, _VP, _VP],

@@ -403,12 +403,21 @@ __global__ __launch_bounds__(64) void k_advance(EngineView E, const int16_t* act
 }
 
 __global__ void k_set_positions(EngineView E, int n, const int32_t* slots, const uint64_t* w,
-                                const uint64_t* b, const int8_t* t, const int8_t* win) {
+                                const uint64_t* b, const int8_t* t, const int8_t* win, int keep_tree) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int g = slots[i];
     E.white[g] = w[i]; E.black[g] = b[i]; E.turn[g] = t[i]; E.winner[g] = win[i];
-    E.root[g] = NODE_NONE; E.used[g] = 0; E.root_mode[g] = 0; E.ply[g] = 0; E.leaf_need[g] = 0;
+    if (!keep_tree) {
+        E.root[g] = NODE_NONE; E.used[g] = 0; E.root_mode[g] = 0; E.ply[g] = 0; E.leaf_need[g] = 0;
+    }
+}
+
+__global__ void k_root_counts(EngineView E, int32_t* out) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= E.B) return;
+    const uint32_t r = E.root[g];
+    out[g] = (r == NODE_NONE) ? -1 : (int32_t)((E.IN[pool_base(E, g) + r] >> 8) & 0xFF);
 }
 
 __global__ __launch_bounds__(64) void k_set_root(EngineView E, int g, int64_t node) {
@@ -531,10 +540,40 @@ static int check_err(az_engine* e, hipStream_t s) {
     return AZ_OK;
 }
 
+static int set_positions_impl(az_engine* e, int32_t n, const int32_t* slots_host,
+                              const uint64_t* white_host, const uint64_t* black_host,
+                              const int8_t* turn_host, const int8_t* winner_host, void* stream,
+                              int keep_tree);
+
 extern "C" int az_engine_set_positions(az_engine* e, int32_t n, const int32_t* slots_host,
                                        const uint64_t* white_host, const uint64_t* black_host,
                                        const int8_t* turn_host, const int8_t* winner_host,
                                        void* stream) {
+    return set_positions_impl(e, n, slots_host, white_host, black_host, turn_host, winner_host, stream, 0);
+}
+
+extern "C" int az_engine_update_positions(az_engine* e, int32_t n, const int32_t* slots_host,
+                                          const uint64_t* white_host, const uint64_t* black_host,
+                                          const int8_t* turn_host, const int8_t* winner_host,
+                                          void* stream) {
+    return set_positions_impl(e, n, slots_host, white_host, black_host, turn_host, winner_host, stream, 1);
+}
+
+extern "C" int az_engine_root_counts(az_engine* e, int32_t* counts_host, void* stream) {
+    AZ_CHECK_ARG(e && counts_host, "az_engine_root_counts: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    int32_t* tmp = reinterpret_cast<int32_t*>(e->stage_slots);
+    hipLaunchKernelGGL(k_root_counts, dim3((e->v.B + 255) / 256), dim3(256), 0, s, e->v, tmp);
+    AZ_HIP(hipGetLastError());
+    AZ_HIP(hipMemcpyAsync(counts_host, tmp, e->v.B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    AZ_HIP(hipStreamSynchronize(s));
+    return AZ_OK;
+}
+
+static int set_positions_impl(az_engine* e, int32_t n, const int32_t* slots_host,
+                              const uint64_t* white_host, const uint64_t* black_host,
+                              const int8_t* turn_host, const int8_t* winner_host, void* stream,
+                              int keep_tree) {
     AZ_CHECK_ARG(e && n >= 0 && n <= e->v.B, "az_engine_set_positions: bad n");
     if (n == 0) return AZ_OK;
     AZ_CHECK_ARG(slots_host && white_host && black_host && turn_host, "az_engine_set_positions: null pointer");
@@ -550,7 +589,7 @@ extern "C" int az_engine_set_positions(az_engine* e, int32_t n, const int32_t* s
     AZ_HIP(hipMemcpyAsync(e->stage_t, turn_host, n, hipMemcpyHostToDevice, s));
     AZ_HIP(hipMemcpyAsync(e->stage_win, winner_host, n, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_set_positions, dim3((n + 255) / 256), dim3(256), 0, s, e->v, n, e->stage_slots,
-                       e->stage_w, e->stage_b, e->stage_t, e->stage_win);
+                       e->stage_w, e->stage_b, e->stage_t, e->stage_win, keep_tree);
     AZ_HIP(hipGetLastError());
     AZ_HIP(hipStreamSynchronize(s));  // the staging buffers and host arrays are free again
     return AZ_OK;

@@ -69,6 +69,24 @@ class Engine:
                 self.h, len(slots), _host_ptr(slots), _host_ptr(white), _host_ptr(black),
                 _host_ptr(turn), _host_ptr(winner), _stream()))
 
+    def update_positions(self, slots, white, black, turn, winner=None):
+        """Like set_positions but keeps the trees."""
+        slots = np.ascontiguousarray(slots, np.int32)
+        white = np.ascontiguousarray(white, np.uint64)
+        black = np.ascontiguousarray(black, np.uint64)
+        turn = np.ascontiguousarray(turn, np.int8)
+        winner = None if winner is None else np.ascontiguousarray(winner, np.int8)
+        with torch.cuda.device(self.device):
+            check(_lib.lib().az_engine_update_positions(
+                self.h, len(slots), _host_ptr(slots), _host_ptr(white), _host_ptr(black),
+                _host_ptr(turn), _host_ptr(winner), _stream()))
+
+    def root_counts(self):
+        k = np.zeros(self.n, np.int32)
+        with torch.cuda.device(self.device):
+            check(_lib.lib().az_engine_root_counts(self.h, _host_ptr(k), _stream()))
+        return k
+
     def reset_all(self):
         n = self.n
         self.set_positions(np.arange(n), np.full(n, 0xFFFF, np.uint64),

@@ -124,6 +124,11 @@ int az_engine_destroy(az_engine* e);
 int az_engine_set_positions(az_engine* e, int32_t n, const int32_t* slots_host,
                             const uint64_t* white_host, const uint64_t* black_host,
                             const int8_t* turn_host, const int8_t* winner_host, void* stream);
+/* Same, but keep each game's tree: for callers that step the game themselves
+ * and pass a child of the old root back as the new root. */
+int az_engine_update_positions(az_engine* e, int32_t n, const int32_t* slots_host,
+                               const uint64_t* white_host, const uint64_t* black_host,
+                               const int8_t* turn_host, const int8_t* winner_host, void* stream);
 int az_engine_get_positions(az_engine* e, uint64_t* white_host, uint64_t* black_host,
                             int8_t* turn_host, int8_t* winner_host, void* stream);
 /* Games with active == 0 are skipped by every step below (the shrinking
@@ -158,6 +163,9 @@ int az_engine_node_children(az_engine* e, int32_t g, int64_t node, int32_t* k_ho
                             double* prior64_host, uint8_t* prior_is64_host,
                             int64_t* child_index_host, uint32_t* node_visits_host,
                             float* node_value_sum_host, int64_t* node_index_host, void* stream);
+
+/* Number of children of every game's root (-1: no root), host array [B]. */
+int az_engine_root_counts(az_engine* e, int32_t* counts_host, void* stream);
 
 /* MCTS.get_action_probs (src/mcts.py:191-225) for every active game, with the
  * temperature schedule of src/parallel_trainer.py:164 when temps_host is NULL

@@ -1,0 +1,151 @@
+"""GPU: the drop-in MCTS / Node surface (alphazero_amd.mcts) — the reference's own
+test semantics (tests/test_mcts.py) plus bit-exact parity of what the Node handles
+report against the reference-generated tree fixtures."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fake_net import TableEvaluator
+from test_oracle_golden import _check_children
+
+pytestmark = pytest.mark.gpu
+
+
+def _game(w, b, turn):
+    from alphazero_amd.game import BreakthroughGame, bits_to_board
+    return BreakthroughGame(board=bits_to_board(int(w), int(b)), turn=int(turn))
+
+
+def _table_mcts(sims):
+    from alphazero_amd.mcts import MCTS
+
+    class TableMCTS(MCTS):
+        """Only the network call is replaced, as in tests/golden/make_golden.py."""
+        table = TableEvaluator()
+
+        def _evaluate(self, engine, planes, need):
+            p, v = self.table(planes.cpu().numpy())
+            engine.probs.copy_(torch.from_numpy(np.ascontiguousarray(p)))
+            engine.values.copy_(torch.from_numpy(np.ascontiguousarray(v)))
+            return engine.probs, engine.values
+    return TableMCTS(None, num_simulations=sims, c_puct=1.5)
+
+
+def _stats(root):
+    acts = list(root.children.keys())
+    ch = [root.children[a] for a in acts]
+    return dict(actions=np.array(acts, np.uint8), N=np.array([c.visit_count for c in ch], np.uint32),
+                W=np.array([c.value_sum for c in ch], np.float32),
+                P=np.array([float(c.prior) for c in ch], np.float64),
+                p_is64=np.array([int(not isinstance(c.prior, np.float32)) for c in ch], np.uint8),
+                root_N=root.visit_count)
+
+
+@pytest.mark.parametrize("S", [2, 100])
+def test_node_handles_report_reference_statistics(golden_dir, S):
+    d = np.load(os.path.join(golden_dir, "tree_tier.npz"))
+    games = [_game(d["white"][g], d["black"][g], d["turn"][g]) for g in range(len(d["white"]))]
+    roots = _table_mcts(S).search_batch(games, None, add_noise=False)
+    for g, r in enumerate(roots):
+        _check_children(_stats(r), d, f"fresh{S}", g)
+
+
+def test_tree_reuse_through_node_handles_matches_reference(golden_dir):
+    """Pass root.children[a] back as the next root, as parallel_trainer.py:195-198 does."""
+    d = np.load(os.path.join(golden_dir, "tree_tier.npz"))
+    sel = d["reuse_games"]
+    m = _table_mcts(int(d["reuse_sims"]))
+    games = [_game(d["white"][g], d["black"][g], d["turn"][g]) for g in sel]
+    roots = [None] * len(games)
+    alive = list(range(len(games)))
+    for ply in range(d["reuse_played"].shape[0]):
+        if not alive:
+            break
+        new = m.search_batch([games[i] for i in alive], [roots[i] for i in alive], add_noise=False)
+        for j, i in enumerate(alive):
+            roots[i] = new[j]
+        for i in list(alive):
+            _check_children(_stats(roots[i]), d, "reuse", (ply, i))
+            probs = m.get_action_probs(roots[i], temperature=1.0)
+            assert np.isclose(probs.sum(), 1.0, atol=1e-5)
+            a = int(d["reuse_played"][ply, i])
+            games[i].step(games[i].decode_action(a))
+            roots[i] = roots[i].children[a] if a in roots[i].children else None
+            if games[i].is_terminal():
+                alive.remove(i)
+
+
+class TestReferenceSemantics:      # tests/test_mcts.py:48-195 with the real (bf16) network
+    @pytest.fixture(scope="class")
+    def mcts(self):
+        from alphazero_amd.mcts import MCTS
+        from alphazero_amd.model import AlphaZeroNet
+        torch.manual_seed(0)
+        model = AlphaZeroNet(num_blocks=2, num_filters=128).cuda().eval()
+        return MCTS(model=model, num_simulations=10, c_puct=1.5, fpu_reduction=0.25, device="cuda")
+
+    def test_search_returns_expanded_root(self, mcts):
+        from alphazero_amd.game import BreakthroughGame
+        from alphazero_amd.mcts import Node
+        root = mcts.search(BreakthroughGame())
+        assert isinstance(root, Node) and root.is_expanded() and len(root.children) == 22
+        assert root.visit_count >= mcts.num_simulations
+        assert sum(c.visit_count for c in root.children.values()) == mcts.num_simulations
+
+    def test_dirichlet_noise_changes_priors(self, mcts):
+        from alphazero_amd.game import BreakthroughGame
+        g = BreakthroughGame()
+        p1 = [c.prior for c in mcts.search(g, add_noise=False).children.values()]
+        p2 = [c.prior for c in mcts.search(g, add_noise=True).children.values()]
+        assert p1 != p2
+        assert all(isinstance(p, np.float32) for p in p1) and all(isinstance(p, float) for p in p2)
+
+    def test_action_probs(self, mcts):
+        from alphazero_amd.game import BreakthroughGame
+        root = mcts.search(BreakthroughGame())
+        p = mcts.get_action_probs(root, temperature=1.0)
+        assert p.shape == (192,) and p.dtype == np.float32 and np.isclose(p.sum(), 1.0, atol=1e-5)
+        p0 = mcts.get_action_probs(root, temperature=0.0)
+        assert p0.max() == 1.0 and np.count_nonzero(p0) == 1
+
+    def test_tree_reuse_adds_visits(self, mcts):
+        from alphazero_amd.game import BreakthroughGame
+        g = BreakthroughGame()
+        root = mcts.search(g)
+        before = root.visit_count
+        root = mcts.search(g, root=root)
+        assert root.visit_count == before + mcts.num_simulations
+
+    def test_play_game_segment_with_generic_model(self):
+        """A duck-typed model (src/mcts.py:248-250) on the CPU: tree on the GPU, network
+        wherever the caller put it."""
+        from alphazero_amd.game import BreakthroughGame
+        from alphazero_amd.mcts import MCTS
+        from alphazero_amd.model import AlphaZeroNet
+        torch.manual_seed(1)
+        np.random.seed(1)
+        m = MCTS(AlphaZeroNet(num_blocks=1, num_filters=16).eval(), num_simulations=12, device="cpu")
+        g = BreakthroughGame()
+        root = None
+        for _ in range(8):
+            root = m.search(g, root=root, add_noise=True)
+            probs = m.get_action_probs(root, temperature=1.0)
+            a = int(np.random.choice(len(probs), p=probs))
+            assert probs[a] > 0 and a in root.children
+            g.step(g.decode_action(a))
+            root = root.children[a]
+        assert not g.is_terminal()
+
+    def test_stale_handle_raises(self, mcts):
+        from alphazero_amd.game import BreakthroughGame
+        from alphazero_amd._lib import AzError
+        g = BreakthroughGame()
+        root = mcts.search(g)
+        a, child = next(iter(root.children.items()))
+        sibling = [c for k, c in root.children.items() if k != a][0]
+        g.step(g.decode_action(a))
+        mcts.search(g, root=child)
+        with pytest.raises(AzError):
+            sibling.children
