@@ -26,8 +26,17 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FLOP_PER_POSITION = 778_732_032          # whole network, 2*MAC
-TOWER_FLOP_PER_POSITION = 775_061_504    # stem + 40 tower convs + SE + policy conv + value conv
+FLOP_PER_POSITION = 778_732_032          # whole 20x128 network, 2*MAC
+
+
+def tower_flop_per_position(blocks):
+    """FLOPs (2*MAC) of what the fused tower kernel computes for one position:
+    stem conv + blocks x (two 3x3 convs + SE) + policy conv + value conv.
+    20 blocks: 775,061,504."""
+    conv = 2 * 64 * 128 * 128 * 9
+    return 2 * 64 * 128 * 27 + blocks * (2 * conv + 12_288) + conv + 2 * 64 * 32 * 128
+
+
 PEAK_BF16_DENSE = 2.5e15
 
 
@@ -87,12 +96,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the self-play engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # AZ_BENCH_BACKEND=gloo rehearses the N > 1 control flow on a box with one GPU: every
+    # rank then shares cuda:0 and the collectives run on CPU tensors.
+    backend = os.environ.get("AZ_BENCH_BACKEND", "nccl")
+    rehearsal = backend != "nccl"
+    torch.cuda.set_device(0 if rehearsal else local_rank)
+    coll_dev = "cpu" if rehearsal else "cuda"
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group(backend)
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from alphazero_amd.model import AlphaZeroNet
     from alphazero_amd.selfplay import SelfPlay
@@ -122,19 +139,59 @@ def main():
     inf.set_timing(False)
     st1 = eng.stats()
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         cnt = torch.tensor([st1[k] - st0[k] for k in ("simulations", "moves", "nn_evals")],
-                           dtype=torch.float64, device="cuda")
+                           dtype=torch.float64, device=coll_dev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         sims, moves, evals = (float(x) for x in cnt.tolist())
         dist.barrier()
     else:
         sims, moves, evals = (float(st1[k] - st0[k]) for k in ("simulations", "moves", "nn_evals"))
 
+    exchange = None
+    if dist is not None:
+        # The two exchange steps of an iteration, timed outside the self-play region on a
+        # synthetic iteration's worth of samples (games x 64 plies per rank):
+        # RCCL all-gather into every rank's replay buffer, then one data-parallel
+        # training step at global batch 1024 with an RCCL gradient all-reduce.
+        try:
+            from alphazero_amd.distributed import all_gather_samples, train_step
+            n_s = args.games * 64
+            g = torch.Generator(device=coll_dev).manual_seed(rank)
+            s_states = (torch.rand((n_s, 3, 8, 8), device=coll_dev, generator=g) > 0.7).float()
+            s_pis = torch.softmax(torch.rand((n_s, 192), device=coll_dev, generator=g), 1)
+            s_wls = torch.tensor([[1.0, 0.0]], device=coll_dev).repeat(n_s, 1)
+            barrier()
+            t1 = time.perf_counter()
+            G = all_gather_samples(s_states, s_pis, s_wls)
+            torch.cuda.synchronize()
+            t_gather = time.perf_counter() - t1
+            train_model = AlphaZeroNet(num_blocks=args.blocks, num_filters=128).to(coll_dev)
+            train_model.load_state_dict(model.state_dict())
+            opt = torch.optim.Adam(train_model.parameters(), lr=1e-3, weight_decay=1e-4)
+            per = max(1, 1024 // world)
+            lo = rank * per
+            batch = (G[0][lo:lo + per], G[1][lo:lo + per], G[2][lo:lo + per])
+            del G
+            train_step(train_model, opt, *batch)          # warm-up (allocator, RCCL channels)
+            barrier()
+            t1 = time.perf_counter()
+            train_step(train_model, opt, *batch)
+            torch.cuda.synchronize()
+            t_train = time.perf_counter() - t1
+            tt = torch.tensor([t_gather, t_train], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            exchange = {"sample_allgather_ms": float(tt[0]) * 1e3, "samples_per_rank": n_s,
+                        "bytes_per_rank": n_s * 1544, "train_step_ms": float(tt[1]) * 1e3,
+                        "train_global_batch": per * world, "backend": backend}
+        except Exception as exc:  # the self-play line must still be printed
+            exchange = {"error": repr(exc)}
+
     if rank == 0:
-        achieved = TOWER_FLOP_PER_POSITION * args.games / (tower_ms * 1e-3) if tower_ms > 0 else 0.0
+        flop_launch = tower_flop_per_position(args.blocks) * args.games
+        achieved = flop_launch / (tower_ms * 1e-3) if tower_ms > 0 else 0.0
         out = {
             "metric": "selfplay_mcts_simulations_per_sec",
             "value": sims / dt,
@@ -157,9 +214,11 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_BF16_DENSE / 1e12,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_DENSE, "traffic": None,
                          "kernel": "k_tower", "launch_ms": tower_ms, "launch_samples": tower_samples,
-                         "flop_per_launch": TOWER_FLOP_PER_POSITION * args.games,
+                         "flop_per_launch": flop_launch,
                          "mean_search_depth": eng.mean_depth()},
         }
+        if exchange is not None:
+            out["exchange"] = exchange
         if world == 1 and args.cpu_seconds > 0:
             cores = min(16, os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(128, args.cpu_seconds, args.blocks, cores)

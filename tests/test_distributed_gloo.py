@@ -1,0 +1,96 @@
+"""World-size-2 gloo tests (CPU) of the N > 1 path: game sharding, the ragged
+sample all-gather and the gradient all-reduce of the data-parallel training step."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from alphazero_amd.distributed import shard_games
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from alphazero_amd.distributed import all_gather_samples, train_step, losses
+        from alphazero_amd.model import AlphaZeroNet
+        torch.set_num_threads(1)
+        # ragged all-gather: rank r contributes 3 + 2 r samples tagged with its rank; rank 1 also tests empty
+        n = 3 + 2 * rank
+        g = torch.Generator().manual_seed(rank)
+        states = torch.full((n, 3, 8, 8), float(rank))
+        policies = torch.rand((n, 192), generator=g)
+        wls = torch.tensor([[1.0, 0.0]] * n) if rank == 0 else torch.tensor([[0.0, 1.0]] * n)
+        S, P, W = all_gather_samples(states, policies, wls)
+        assert S.shape[0] == sum(3 + 2 * r for r in range(world))
+        assert torch.all(S[:3] == 0.0) and torch.all(S[3:] == 1.0)
+        assert torch.equal(P[3:] if rank == 1 else P[:3], policies)
+        assert torch.all(W[:3, 0] == 1.0) and torch.all(W[3:, 1] == 1.0)
+        E = all_gather_samples(states[:0], policies[:0], wls[:0]) if rank == 1 else \
+            all_gather_samples(states, policies, wls)
+        assert E[0].shape[0] == 3                      # rank 1 sent nothing this time
+        # data-parallel step == single-process step on the concatenated batch (no BatchNorm
+        # difference here: compare gradients computed in eval-mode statistics)
+        torch.manual_seed(0)
+        model = AlphaZeroNet(num_blocks=1, num_filters=16)
+        ref = AlphaZeroNet(num_blocks=1, num_filters=16)
+        ref.load_state_dict(model.state_dict())
+        gb = torch.Generator().manual_seed(7)
+        X = (torch.rand((8, 3, 8, 8), generator=gb) > 0.5).float()
+        PI = torch.softmax(torch.rand((8, 192), generator=gb), 1)
+        WL = torch.tensor([[1.0, 0.0], [0.0, 1.0]] * 4)
+        lo, hi = shard_games(8, rank, world)
+        model.eval()                                    # freeze BN statistics for an exact comparison
+        loss, _, _ = losses(model, X[lo:hi], PI[lo:hi], WL[lo:hi])
+        model.zero_grad()
+        loss.backward()
+        from alphazero_amd.distributed import allreduce_mean_gradients
+        allreduce_mean_gradients(model, bucket_bytes=4096)     # several buckets
+        ref.eval()
+        rl, _, _ = losses(ref, X, PI, WL)
+        ref.zero_grad()
+        rl.backward()
+        for (k, p), q in zip(model.named_parameters(), ref.parameters()):
+            assert torch.allclose(p.grad, q.grad, atol=1e-5), k
+        # the full step keeps the replicas identical
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+        train_step(model, opt, X[lo:hi], PI[lo:hi], WL[lo:hi])
+        flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+        both = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        assert torch.equal(both[0], both[1])
+        ret[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_games():
+    assert [shard_games(8192, r, 8) for r in (0, 7)] == [(0, 1024), (7168, 8192)]
+    spans = [shard_games(10, r, 4) for r in range(4)]
+    assert spans == [(0, 3), (3, 6), (6, 8), (8, 10)]
+
+
+def test_two_rank_gloo_exchange_steps():
+    world = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert dict(ret) == {0: 1, 1: 1}
