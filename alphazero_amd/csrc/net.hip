@@ -86,6 +86,15 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
     bf16x2 v = {(__bf16)a, (__bf16)b};
     return *reinterpret_cast<uint32_t*>(&v);
 }
+// ReLU on two packed bf16 values: as signed 16-bit integers every negative float is
+// negative, so one v_pk_max_i16 against zero clamps both (-0.0 becomes +0.0)
+__device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v) {
+    typedef __attribute__((ext_vector_type(2))) short short2_t;
+    short2_t x = *reinterpret_cast<short2_t*>(&v);
+    const short2_t z = {0, 0};
+    x = __builtin_elementwise_max(x, z);
+    return *reinterpret_cast<uint32_t*>(&x);
+}
 __device__ __forceinline__ float bf16_lo(uint32_t v) { return __uint_as_float(v << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t v) { return __uint_as_float(v & 0xFFFF0000u); }
 
@@ -144,6 +153,18 @@ __device__ __forceinline__ void mma_step(f32x16 (&acc)[4][2], const Frags& f) {
     }
 }
 
+// Scheduling recipe for one pipeline step: MFMA, DS read, MFMA, DS read, ... then the
+// remaining MFMAs; ends with a full scheduling barrier so steps stay in source order.
+__device__ __forceinline__ void interleave_step() {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one DS read
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // acc[nt][pt][v] + bias -> optional ReLU -> bf16 -> the wave's LDS region, and
 // (optionally) the packed copy kept in registers as the next residual.
 template <bool RELU, bool KEEP, bool BIAS>
@@ -163,14 +184,11 @@ __device__ __forceinline__ void store_act(char* region, const f32x16 (&acc)[4][2
                 float v1 = acc[nt][pt][gq * 4 + 1] + b[1];
                 float v2 = acc[nt][pt][gq * 4 + 2] + b[2];
                 float v3 = acc[nt][pt][gq * 4 + 3] + b[3];
-                if (RELU) {
-                    v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-                }
-                const uint32_t lo = pack_bf16x2(v0, v1), hi = pack_bf16x2(v2, v3);
+                uint32_t lo = pack_bf16x2(v0, v1), hi = pack_bf16x2(v2, v3);
+                if (RELU) { lo = relu_bf16x2(lo); hi = relu_bf16x2(hi); }
                 if (KEEP) { keep[nt][pt][gq * 2 + 0] = lo; keep[nt][pt][gq * 2 + 1] = hi; }
                 *reinterpret_cast<uint2*>(region + (pt * 32 + r) * ACT_PITCH + ch0 * 2) = make_uint2(lo, hi);
             }
-            __builtin_amdgcn_sched_barrier(0);  // keep the groups apart: hoisting all reads up front spills
         }
     }
 }
@@ -211,6 +229,7 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
                    __builtin_amdgcn_readfirstlane(lds_base + LDS_SE + piece * 1024));
     };
     prefetch(0);
+    prefetch_bias(0);
 
     // per-tap fragment addresses (bytes from the LDS base) for the two pixel tiles
     uint32_t aaddr[9][2];
@@ -269,12 +288,19 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
     __syncthreads();  // tap 0 landed, zero row visible
 
     for (int conv = 0; conv < nconv; ++conv) {
+        // the accumulators start from the folded-BN bias of this conv (in LDS since the
+        // previous conv), so no epilogue has to add it
+        {
+            const float* b0 = reinterpret_cast<const float*>(lds + LDS_BIAS + (conv & 1) * 512) + h * 4;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int pt = 0; pt < 2; ++pt)
+                for (int gq = 0; gq < 4; ++gq) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(b0 + nt * 32 + gq * 8);
 #pragma unroll
-                for (int v = 0; v < 16; ++v) acc[nt][pt][v] = 0.f;
+                    for (int q = 0; q < 4; ++q) { acc[nt][0][gq * 4 + q] = b[q]; acc[nt][1][gq * 4 + q] = b[q]; }
+                }
+        }
         // Software pipeline: the fragments of k-step s+1 are read from LDS while the
         // 8 MFMAs of k-step s run.  The workgroup barrier of a tap sits between its
         // k-steps 6 and 7 (k-step 7's fragments are in registers by then), so the
@@ -285,26 +311,29 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
         for (int tap = 0; tap < 9; ++tap) {
             const int T = conv * 9 + tap;
             if (T + 1 < total_taps) prefetch(T + 1);
-            if (tap == 0) prefetch_bias(conv);
+            if (tap == 0 && conv + 1 < nconv) prefetch_bias(conv + 1);
             if ((conv & 1) && tap < 7 && conv < nconv - 1) prefetch_se(conv >> 1, tap * 4 + wave_u);
             const uint32_t wb = LDS_W + (T & 1) * TAP_BYTES + lane * 16;
             const uint32_t wb_next = LDS_W + ((T + 1) & 1) * TAP_BYTES + lane * 16;
 #pragma unroll
             for (int ks = 0; ks < 8; ks += 2) {
+                // one pipeline step = 6 fragment reads (for the step after) + 8 MFMAs; the reads
+                // are spread one per MFMA so that each issues in an MFMA's shadow
                 load_frags(f1, lds, aaddr[tap][0], aaddr[tap][1], wb, ks + 1);
-                __builtin_amdgcn_sched_barrier(0);
                 mma_step(acc, f0);
-                __builtin_amdgcn_sched_barrier(0);
+                interleave_step();
                 if (ks + 2 < 8) {
                     load_frags(f0, lds, aaddr[tap][0], aaddr[tap][1], wb, ks + 2);
+                    mma_step(acc, f1);
+                    interleave_step();
                 } else {
+                    __builtin_amdgcn_sched_barrier(0);
                     wait_weights();
                     __syncthreads();  // next tap landed; everyone is done reading this buffer
                     if (tap + 1 < 9) load_frags(f0, lds, aaddr[tap + 1 < 9 ? tap + 1 : 0][0], aaddr[tap + 1 < 9 ? tap + 1 : 0][1], wb_next, 0);
+                    mma_step(acc, f1);
+                    interleave_step();
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                mma_step(acc, f1);
-                __builtin_amdgcn_sched_barrier(0);
             }
         }
         // Epilogue addresses are rebuilt from an opaque zero on every pass: left
@@ -314,10 +343,9 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
         asm volatile("v_mov_b32 %0, 0" : "=v"(oz));
         char* lds_e = lds + oz;
         char* region = lds_e + wave * ACT_REGION;
-        const float* bias = reinterpret_cast<const float*>(lds_e + LDS_BIAS + (conv & 1) * 512);
         if (conv == nconv - 1) {
             // ---- policy conv: + bias, ReLU -> LDS -> p_act (coalesced 16 B per lane)
-            store_act<true, false, true>(region, acc, bias, resid, r, h);
+            store_act<true, false, false>(region, acc, nullptr, resid, r, h);
             if (live) {
                 char* out = reinterpret_cast<char*>(p.p_act) + (size_t)pos * 64 * CH * 2;
 #pragma unroll
@@ -329,19 +357,18 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
             }
         } else if ((conv & 1) == 0) {
             // ---- conv1 of a block: + bias, ReLU -> LDS
-            store_act<true, false, true>(region, acc, bias, resid, r, h);
+            store_act<true, false, false>(region, acc, nullptr, resid, r, h);
         } else {
             // ---- conv2 of a block: + bias, SE, + residual, ReLU -> LDS and registers
             float* scratch = reinterpret_cast<float*>(region);  // the region is free now
             const float* se = reinterpret_cast<const float*>(lds_e + LDS_SE);
             if (p.dbg & 1) {
-                store_act<true, true, true>(region, acc, bias, resid, r, h);
+                store_act<true, true, false>(region, acc, nullptr, resid, r, h);
                 continue;
             }
-            // Squeeze: per-channel mean of z = acc + bias over the 64 pixels.  Per channel
-            // tile the 16 per-lane partial sums are reduce-scattered over the 32 lanes of
-            // each half (16 shuffles per tile instead of 16 x 5); acc itself is left
-            // untouched, the bias enters through the mean and through the shift below.
+            // Squeeze: per-channel mean of z (= acc, bias included) over the 64 pixels.  Per
+            // channel tile the 16 per-lane partial sums are reduce-scattered over the 32
+            // lanes of each half (16 shuffles per tile instead of 16 x 5).
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 f32x16 v = acc[nt][0] + acc[nt][1];  // a register vector: constant indices only
@@ -363,8 +390,7 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
                 const float tot = v[0] + __shfl_xor(v[0], 1);
                 const int idx = r >> 1;  // accumulator register index this lane pair reduced
                 const int ch = nt * 32 + (idx >> 2) * 8 + h * 4 + (idx & 3);
-                if ((r & 1) == 0) scratch[ch] = tot * (1.0f / 64.0f) + bias[ch];
-                __builtin_amdgcn_sched_barrier(0);
+                if ((r & 1) == 0) scratch[ch] = tot * (1.0f / 64.0f);
             }
             wave_lds_sync();
             // fc1 (128 -> 16) + ReLU: lane = (j = lane&15, quarter = lane>>4)
@@ -385,7 +411,7 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
             }
             wave_lds_sync();
             // fc2 (16 -> 256) from the transposed weights: this lane computes the gate
-            // and the shift of channels lane and lane + 64; shift absorbs bias * gate
+            // and the shift of channels lane and lane + 64
             {
                 f32x4 hid[4];
 #pragma unroll
@@ -402,7 +428,7 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
                     }
                     g = 1.0f / (1.0f + __expf(-g));  // sigmoid
                     scratch[160 + c] = g;
-                    scratch[160 + CH + c] = sh + bias[c] * g;
+                    scratch[160 + CH + c] = sh;
                 }
             }
             wave_lds_sync();
@@ -422,7 +448,6 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
                         acc[nt][pt][gq * 4 + 2] = acc[nt][pt][gq * 4 + 2] * gt[2] + sh[2] + bf16_lo(rhi);
                         acc[nt][pt][gq * 4 + 3] = acc[nt][pt][gq * 4 + 3] * gt[3] + sh[3] + bf16_hi(rhi);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             store_act<true, true, false>(region, acc, nullptr, resid, r, h);
