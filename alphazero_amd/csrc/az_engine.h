@@ -44,6 +44,7 @@ struct EngineView {
     uint32_t* IN;
     int32_t* err;
     unsigned long long *stat_depth, *stat_descents;
+    unsigned long long *stat_terminal, *stat_rootexp;  // terminal leaves backed up, roots expanded
 };
 
 struct NodeQuery {
@@ -113,7 +114,7 @@ struct SelfplayView {
     float* q_pi;            // [Q][192]
     uint32_t* q_count;      // samples in the queue
     uint32_t q_cap;
-    unsigned long long* stat;  // [0] moves, [1] games finished, [2] network evaluations
+    unsigned long long* stat;  // [0] moves, [1] games finished
 };
 
 }  // namespace az

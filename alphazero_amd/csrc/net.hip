@@ -29,6 +29,8 @@
 #include <vector>
 
 #include "az_common.h"
+#include "head_dev.h"
+#include "net_internal.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -58,11 +60,8 @@ constexpr int LDS_TOTAL = LDS_SE + SE_BYTES;           // 163328 <= 163840
 constexpr int CONV_BYTES = 9 * TAP_BYTES;      // 294912
 constexpr int VALUE_CH = 32;
 constexpr int SE_HID = 16;
-constexpr int HEAD_KCHUNK = 1024;
 constexpr int POLICY_K = 64 * CH;              // 8192
 constexpr int VALUE_K = 64 * VALUE_CH;         // 2048
-constexpr int POLICY_CHUNKS = POLICY_K / HEAD_KCHUNK;  // 8
-constexpr int VALUE_CHUNKS = VALUE_K / HEAD_KCHUNK;    // 2
 
 struct TowerParams {
     const uint64_t* mine;       // [B] canonical bitboards
@@ -81,9 +80,14 @@ struct TowerParams {
     int dbg;                    // diagnostic ablation flags (AZ_TOWER_DBG), 0 in production
 };
 
+// two floats -> packed bf16 (round to nearest even) in ONE v_cvt_pk_bf16_f32: the
+// conversion has to be written on the 2-vector, element-wise casts cost two
+// conversions plus a v_perm_b32 each
 __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-    bf16x2 v = {(__bf16)a, (__bf16)b};
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    const f32x2 f = {a, b};
+    bf16x2 v = __builtin_convertvector(f, bf16x2);
     return *reinterpret_cast<uint32_t*>(&v);
 }
 // ReLU on two packed bf16 values: as signed 16-bit integers every negative float is
@@ -542,70 +546,16 @@ __global__ __launch_bounds__(256) void k_head_gemm(HeadParams p) {
         head_gemm_body<2, 8>(p.v_act, VALUE_K, p.wv, p.part_v, 128, p.B, c - POLICY_CHUNKS, tile, wave, lane);
 }
 
-struct FinishParams {
-    const float* part_p; const float* part_v;
-    const float* bp;   // [192]
-    const float* bv1;  // [128]
-    const float* wv2;  // [2][128]
-    const float* bv2;  // [2]
-    float* probs; float* value; float* policy_logits; float* wl_logits;
-    int B;
-};
-
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-
 // one wave per position
 __global__ __launch_bounds__(256) void k_head_finish(FinishParams p) {
     const int lane = threadIdx.x & 63;
     const int pos = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pos >= p.B) return;
-    float lg[3];
+    float pr[3];
+    const float value = dev_head_finish(p, pos, lane, pr);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int n = lane + 64 * i;
-        float s = p.bp[n];
-#pragma unroll
-        for (int c = 0; c < POLICY_CHUNKS; ++c) s += p.part_p[((size_t)c * p.B + pos) * NUM_ACTIONS + n];
-        lg[i] = s;
-        if (p.policy_logits) p.policy_logits[(size_t)pos * NUM_ACTIONS + n] = s;
-    }
-    const float mx = wave_max(fmaxf(lg[0], fmaxf(lg[1], lg[2])));
-    float e[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) e[i] = __expf(lg[i] - mx);
-    const float inv = 1.0f / wave_sum(e[0] + e[1] + e[2]);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) p.probs[(size_t)pos * NUM_ACTIONS + lane + 64 * i] = e[i] * inv;
-    // value head: hidden = relu(fc1), wl = fc2(hidden)
-    float w0 = 0.f, w1 = 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int n = lane + 64 * i;
-        float s = p.bv1[n];
-#pragma unroll
-        for (int c = 0; c < VALUE_CHUNKS; ++c) s += p.part_v[((size_t)c * p.B + pos) * 128 + n];
-        s = fmaxf(s, 0.f);
-        w0 += s * p.wv2[n];
-        w1 += s * p.wv2[128 + n];
-    }
-    w0 = wave_sum(w0) + p.bv2[0];
-    w1 = wave_sum(w1) + p.bv2[1];
-    if (lane == 0) {
-        if (p.wl_logits) { p.wl_logits[2 * pos] = w0; p.wl_logits[2 * pos + 1] = w1; }
-        const float m = fmaxf(w0, w1);
-        const float e0 = __expf(w0 - m), e1 = __expf(w1 - m);
-        const float is = 1.0f / (e0 + e1);
-        p.value[pos] = e0 * is - e1 * is;   // P(win) - P(loss), src/mcts.py:256
-    }
+    for (int i = 0; i < 3; ++i) p.probs[(size_t)pos * NUM_ACTIONS + lane + 64 * i] = pr[i];
+    if (lane == 0) p.value[pos] = value;
 }
 
 // planes [B][3][8][8] float32 (0/1 values, third plane ones) -> canonical bitboards
@@ -884,14 +834,13 @@ extern "C" int az_net_load_state(az_net* n, const float* s, int64_t count) {
     return AZ_OK;
 }
 
-extern "C" int az_net_forward(az_net* n, int32_t B, const uint64_t* mine_dev, const uint64_t* theirs_dev,
-                              float* probs_dev, float* value_dev, float* policy_logits_dev,
-                              float* wl_logits_dev, void* stream) {
+// tower + head GEMMs: leaves the split-K partial sums in the network's buffers
+int az::net_forward_partial(az_net* n, int32_t B, const uint64_t* mine_dev, const uint64_t* theirs_dev,
+                            hipStream_t s) {
     AZ_CHECK_ARG(n && n->loaded, "az_net_forward: network has no weights (call az_net_load_state)");
     AZ_CHECK_ARG(B >= 0 && B <= n->max_batch, "az_net_forward: batch %d exceeds max_batch %d", B, n->max_batch);
     if (B == 0) return AZ_OK;
-    AZ_CHECK_ARG(mine_dev && theirs_dev && probs_dev && value_dev, "az_net_forward: null pointer");
-    hipStream_t s = (hipStream_t)stream;
+    AZ_CHECK_ARG(mine_dev && theirs_dev, "az_net_forward: null pointer");
     TowerParams tp;
     tp.mine = mine_dev; tp.theirs = theirs_dev; tp.B = B; tp.blocks = n->blocks;
     tp.stem_w = n->stem_w; tp.stem_b = n->stem_b; tp.conv_w = n->conv_w; tp.conv_b = n->conv_b;
@@ -905,8 +854,23 @@ extern "C" int az_net_forward(az_net* n, int32_t B, const uint64_t* mine_dev, co
     if (stamp) AZ_HIP(hipEventRecord(n->ev1[n->ev_used++], s));
     HeadParams hp{n->p_act, n->v_act, n->wp, n->wv, n->part_p, n->part_v, B};
     hipLaunchKernelGGL(k_head_gemm, dim3((B + 15) / 16, POLICY_CHUNKS + VALUE_CHUNKS), dim3(256), 0, s, hp);
-    FinishParams fp{n->part_p, n->part_v, n->bp, n->bv1, n->wv2, n->bv2, probs_dev, value_dev,
-                    policy_logits_dev, wl_logits_dev, B};
+    AZ_HIP(hipGetLastError());
+    return AZ_OK;
+}
+
+az::FinishParams az::net_finish_params(az_net* n, int32_t B) {
+    return FinishParams{n->part_p, n->part_v, n->bp, n->bv1, n->wv2, n->bv2, nullptr, nullptr, nullptr, nullptr, B};
+}
+
+extern "C" int az_net_forward(az_net* n, int32_t B, const uint64_t* mine_dev, const uint64_t* theirs_dev,
+                              float* probs_dev, float* value_dev, float* policy_logits_dev,
+                              float* wl_logits_dev, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const int rc = az::net_forward_partial(n, B, mine_dev, theirs_dev, s);
+    if (rc != AZ_OK || B == 0) return rc;
+    AZ_CHECK_ARG(probs_dev && value_dev, "az_net_forward: null pointer");
+    FinishParams fp = az::net_finish_params(n, B);
+    fp.probs = probs_dev; fp.value = value_dev; fp.policy_logits = policy_logits_dev; fp.wl_logits = wl_logits_dev;
     hipLaunchKernelGGL(k_head_finish, dim3((B + 3) / 4), dim3(256), 0, s, fp);
     AZ_HIP(hipGetLastError());
     return AZ_OK;

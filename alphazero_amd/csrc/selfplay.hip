@@ -3,7 +3,8 @@
 // (src/parallel_trainer.py:158-217) entirely on the device.
 //
 // Compile with -ffp-contract=off (shares the exact float32 rules of tree.hip).
-#include "az_engine.h"
+#include "net_internal.h"
+#include "tree_dev.h"
 
 extern "C" int az_net_forward(struct az_net* n, int32_t B, const uint64_t* mine_dev,
                               const uint64_t* theirs_dev, float* probs_dev, float* value_dev,
@@ -140,12 +141,30 @@ __global__ void k_unpack_samples(SelfplayView S, uint32_t n, float* states, floa
     if (lane < 2) wls[2 * (size_t)q + lane] = S.q_wl[2 * (size_t)q + lane];
 }
 
-__global__ void k_count_evals(EngineView E, SelfplayView S) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long c = 0;
-    if (g < E.B && E.active[g] && E.leaf_need[g]) c = 1;
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&S.stat[2], c);
+// One simulation's tree work for one game in ONE launch: finish the network heads for
+// the leaf (softmax / value), expand it, back the value up, then run the next
+// simulation's PUCT descent (src/mcts.py:153-187).
+__global__ __launch_bounds__(64) void k_tree_step(EngineView E, FinishParams F, int do_select) {
+    __shared__ float s_probs[192];
+    __shared__ float s_p[MAX_CHILDREN];
+    __shared__ uint8_t s_a[MAX_CHILDREN];
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (!E.active[g]) return;
+    const int need = E.leaf_need[g];
+    float v = E.leaf_tv[g];
+    if (need) {
+        float pr[3];
+        v = dev_head_finish(F, g, lane, pr);
+        s_probs[lane] = pr[0]; s_probs[lane + 64] = pr[1]; s_probs[lane + 128] = pr[2];
+        __syncthreads();
+        dev_expand(E, g, lane, s_probs, s_p, s_a);
+    }
+    dev_backup(E, g, lane, v);
+    if (lane == 0) E.leaf_need[g] = 0;
+    if (do_select) {
+        __syncthreads();  // this wave's tree updates are visible to its own descent
+        dev_select(E, g, lane, nullptr, nullptr);
+    }
 }
 
 }  // namespace az
@@ -195,7 +214,8 @@ static int check_sticky(az_engine* e, hipStream_t s) {
     return AZ_OK;
 }
 
-// MCTS.search_batch (src/mcts.py:94-189) with the attached network
+// MCTS.search_batch (src/mcts.py:94-189) with the attached network.  Per simulation
+// three launches: tower, head GEMMs, k_tree_step.
 static int search_async(az_engine* e, int num_simulations, int add_noise, hipStream_t s) {
     if (!e->net) AZ_FAIL(AZ_ERR_STATE, "no network attached (az_engine_attach_net)");
     const int B = e->v.B;
@@ -203,17 +223,16 @@ static int search_async(az_engine* e, int num_simulations, int add_noise, hipStr
     if ((rc = az_engine_roots_prepare(e, nullptr, nullptr, s))) return rc;
     if ((rc = az_net_forward(e->net, B, e->v.leaf_mine, e->v.leaf_theirs, e->nn_probs, e->nn_values, nullptr,
                              nullptr, s))) return rc;
-    hipLaunchKernelGGL(k_count_evals, dim3((B + 255) / 256), dim3(256), 0, s, e->v, e->sp);
     if ((rc = az_engine_roots_expand(e, e->nn_probs, s))) return rc;
     if (add_noise && (rc = az_engine_add_noise(e, nullptr, s))) return rc;
+    if (num_simulations > 0 && (rc = az_engine_select(e, nullptr, nullptr, s))) return rc;
+    const FinishParams fin = az::net_finish_params(e->net, B);
     for (int i = 0; i < num_simulations; ++i) {
-        if ((rc = az_engine_select(e, nullptr, nullptr, s))) return rc;
-        if ((rc = az_net_forward(e->net, B, e->v.leaf_mine, e->v.leaf_theirs, e->nn_probs, e->nn_values,
-                                 nullptr, nullptr, s))) return rc;
-        hipLaunchKernelGGL(k_count_evals, dim3((B + 255) / 256), dim3(256), 0, s, e->v, e->sp);
-        if ((rc = az_engine_expand_backup(e, e->nn_probs, e->nn_values, s))) return rc;
+        if ((rc = az::net_forward_partial(e->net, B, e->v.leaf_mine, e->v.leaf_theirs, s))) return rc;
+        hipLaunchKernelGGL(k_tree_step, dim3(B), dim3(64), 0, s, e->v, fin, i + 1 < num_simulations ? 1 : 0);
     }
     AZ_HIP(hipGetLastError());
+    e->phase = PHASE_IDLE;
     return AZ_OK;
 }
 
@@ -280,7 +299,11 @@ extern "C" int az_engine_selfplay_stats(az_engine* e, az_selfplay_stats* out, vo
     AZ_HIP(hipMemcpyAsync(&sims, e->v.stat_descents, sizeof sims, hipMemcpyDeviceToHost, s));
     AZ_HIP(hipMemcpyAsync(&q, e->sp.q_count, sizeof q, hipMemcpyDeviceToHost, s));
     AZ_HIP(hipStreamSynchronize(s));
-    out->simulations = sims; out->nn_evals = st[2]; out->moves = st[0]; out->games_finished = st[1];
+    unsigned long long term = 0, rootexp = 0;
+    AZ_HIP(hipMemcpy(&term, e->v.stat_terminal, sizeof term, hipMemcpyDeviceToHost));
+    AZ_HIP(hipMemcpy(&rootexp, e->v.stat_rootexp, sizeof rootexp, hipMemcpyDeviceToHost));
+    // every descent that did not end in a terminal leaf was evaluated, plus the root expansions
+    out->simulations = sims; out->nn_evals = sims - term + rootexp; out->moves = st[0]; out->games_finished = st[1];
     out->samples_pending = q;
     return AZ_OK;
 }

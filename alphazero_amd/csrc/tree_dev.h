@@ -1,0 +1,203 @@
+// Device-side building blocks of the tree search, shared by the step kernels
+// (tree.hip) and the fused per-simulation kernel (selfplay.hip).
+//
+// Every translation unit that includes this must be compiled with
+// -ffp-contract=off: q + u and the prior arithmetic are separately rounded
+// float32 operations in the reference (src/mcts.py:299-305, 264-279).
+#pragma once
+#include "az_engine.h"
+
+namespace az {
+
+// planes [3][8][8] float32 of a canonical position: 48 lanes x 16 B
+__device__ inline void write_planes(float* dst, uint64_t mine, uint64_t theirs, int lane) {
+    if (lane < 48) {
+        const int p = lane >> 4;
+        const int s0 = (4 * lane) & 63;
+        const uint64_t src = (p == 0) ? mine : ((p == 1) ? theirs : ~0ull);
+        float4 v;
+        v.x = (float)((src >> (s0 + 0)) & 1ull);
+        v.y = (float)((src >> (s0 + 1)) & 1ull);
+        v.z = (float)((src >> (s0 + 2)) & 1ull);
+        v.w = (float)((src >> (s0 + 3)) & 1ull);
+        reinterpret_cast<float4*>(dst)[lane] = v;
+    }
+}
+
+// game g's live arena (two arenas per game; re-rooting copies the kept subtree
+// into the other one)
+__device__ inline size_t pool_base(const EngineView& E, int g) {
+    return ((size_t)g * 2 + E.arena[g]) * E.cap;
+}
+
+__device__ inline double wave_max_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double other = __shfl_xor(v, o);
+        v = (other > v) ? other : v;
+    }
+    return v;
+}
+
+__device__ inline uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ inline double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// One PUCT descent of game g by one wave: src/mcts.py:153-171 with _select_child (:281-312)
+__device__ inline void dev_select(const EngineView& E, int g, int lane, float* planes, uint8_t* need_eval) {
+    if (!E.active[g]) {
+        if (lane == 0) { E.leaf_need[g] = 0; if (need_eval) need_eval[g] = 0; }
+        return;
+    }
+    const size_t pool = pool_base(E, g);
+    const uint32_t r = E.root[g];
+    const int rmode = E.root_mode[g];
+    int t = E.turn[g];
+    int win = E.winner[g];
+    uint64_t mine, theirs;
+    {
+        const uint64_t w = E.white[g], b = E.black[g];
+        mine = (t > 0) ? w : bitrev64(b);
+        theirs = (t > 0) ? b : bitrev64(w);
+    }
+    uint32_t node = r;
+    uint32_t* path = E.path + (size_t)g * MAX_DEPTH;
+    int depth = 1;
+    if (lane == 0) path[0] = node;
+    const float cp32 = (float)E.c_puct;
+    while (true) {
+        const uint32_t inf = E.IN[pool + node];
+        const int k = (inf >> 8) & 0xFF;
+        if (k == 0) break;
+        if (depth >= MAX_DEPTH) { if (lane == 0) atomicOr(E.err, ERR_DEPTH); break; }
+        const uint32_t fc = E.FC[pool + node];
+        const uint32_t pn = E.N[pool + node];
+        const double sqrt_parent = sqrt((double)(pn > 1 ? pn : 1));
+        const bool root64 = (node == r) && rmode;
+        const bool f64mode = root64 || ((inf >> 16) & FLAG_UNIFORM64);
+        double score = -INFINITY;
+        uint32_t cinfo = 0;
+        if (lane < k) {
+            const uint32_t cN = E.N[pool + fc + lane];
+            const float cW = E.W[pool + fc + lane];
+            cinfo = E.IN[pool + fc + lane];
+            if (!f64mode) {
+                const float cP = E.P[pool + fc + lane];
+                const float q = (cN == 0) ? 0.0f : -(cW / (float)cN);
+                float u = cp32 * cP;
+                u = u * (float)sqrt_parent;
+                u = u / (float)(1u + cN);
+                const float s = q + u;
+                score = (double)s;
+            } else {
+                const double p64 = root64 ? E.root_p64[(size_t)g * 48 + lane] : 1.0 / (double)k;
+                const double q = (cN == 0) ? 0.0 : (double)(-(cW / (float)cN));
+                double u = E.c_puct * p64;
+                u = u * sqrt_parent;
+                u = u / (double)(1u + cN);
+                score = q + u;
+            }
+        }
+        // argmax with ties to the lowest child slot (strict '>' in insertion order)
+        const double best = wave_max_f64(score);
+        const unsigned long long tie = __ballot(score == best);
+        const int bl = (tie == 0) ? 0 : (__ffsll((long long)tie) - 1);
+        const int a = __shfl((int)(cinfo & 0xFF), bl);
+        // decode_action + step in canonical coordinates (src/game.py:257-278, 156-187)
+        const int sq = a / 3, d = a - 3 * sq;
+        const int to = sq + ((d == 0) ? 8 : ((d == 1) ? 7 : 9));
+        const uint64_t fb = 1ull << sq, tb = 1ull << (to & 63);
+        mine = (mine & ~fb) | tb;
+        theirs &= ~tb;
+        if (to >= 56) win = t;
+        if (win == 0 && theirs == 0) win = t;
+        const uint64_t nm = bitrev64(theirs), nt = bitrev64(mine);
+        mine = nm; theirs = nt; t = -t;
+        node = fc + bl;
+        if (lane == 0) path[depth] = node;
+        ++depth;
+    }
+    const Legal3 l = legal_sources(mine, theirs);
+    const bool terminal = (win != 0) || ((l.fwd | l.dl | l.dr) == 0);
+    if (lane == 0) {
+        E.leaf_node[g] = node; E.leaf_mine[g] = mine; E.leaf_theirs[g] = theirs;
+        E.leaf_turn[g] = (int8_t)t; E.path_len[g] = (uint16_t)depth;
+        E.leaf_need[g] = terminal ? 0 : 1;
+        // src/mcts.py:328-335: result seen by the side to move at the leaf
+        E.leaf_tv[g] = (win != 0) ? ((win == t) ? 1.0f : -1.0f) : -1.0f;
+        if (need_eval) need_eval[g] = terminal ? 0 : 1;
+        atomicAdd(E.stat_depth, (unsigned long long)(depth - 1));
+        if (terminal) atomicAdd(E.stat_terminal, 1ull);
+    }
+    if (!terminal && planes) write_planes(planes + (size_t)g * 192, mine, theirs, lane);
+}
+
+// ---------------------------------------------------------------------------
+// _expand_node (src/mcts.py:260-279).  pr: the 192 softmaxed policy values of this
+// leaf (global or LDS); s_p / s_a: 48-entry LDS scratch.  One wave, all lanes.
+__device__ inline void dev_expand(const EngineView& E, int g, int lane, const float* pr, float* s_p,
+                                  uint8_t* s_a) {
+    const size_t pool = pool_base(E, g);
+    const uint64_t mine = E.leaf_mine[g], theirs = E.leaf_theirs[g];
+    const int t = E.leaf_turn[g];
+    const uint32_t leaf = E.leaf_node[g];
+    const Legal3 l = legal_sources(mine, theirs);
+    const int k = __popcll(l.fwd) + __popcll(l.dl) + __popcll(l.dr);
+    // insertion order (src/game.py:117-118 scans the REAL board row-major):
+    // White = ascending canonical squares, Black = descending
+    const int sq = lane;
+    const uint64_t before = (t > 0) ? ((1ull << sq) - 1ull)
+                                    : ((sq == 63) ? 0ull : (~0ull << (sq + 1)));
+    int rank = __popcll(l.fwd & before) + __popcll(l.dl & before) + __popcll(l.dr & before);
+    if ((l.fwd >> sq) & 1ull) { s_a[rank] = (uint8_t)(sq * 3 + 0); s_p[rank] = pr[sq * 3 + 0]; ++rank; }
+    if ((l.dl >> sq) & 1ull)  { s_a[rank] = (uint8_t)(sq * 3 + 1); s_p[rank] = pr[sq * 3 + 1]; ++rank; }
+    if ((l.dr >> sq) & 1ull)  { s_a[rank] = (uint8_t)(sq * 3 + 2); s_p[rank] = pr[sq * 3 + 2]; ++rank; }
+    __syncthreads();
+    const float p_r = (lane < k) ? s_p[lane] : 0.f;
+    const uint32_t a_r = (lane < k) ? s_a[lane] : 0;
+    float prior_sum = 0.0f;                       // sequential float32 sum, insertion order
+    for (int i = 0; i < k; ++i) prior_sum = prior_sum + __shfl(p_r, i);
+    if (k > 0) {
+        const uint32_t base = E.used[g];
+        if ((uint64_t)base + (uint64_t)k > (uint64_t)E.cap) {
+            if (lane == 0) atomicOr(E.err, ERR_POOL);
+        } else {
+            if (lane < k) {
+                const size_t c = pool + base + lane;
+                E.N[c] = 0; E.W[c] = 0.f; E.FC[c] = 0; E.IN[c] = a_r;
+                E.P[c] = (prior_sum > 0) ? (p_r / prior_sum) : (float)(1.0 / (double)k);
+            }
+            if (lane == 0) {
+                E.used[g] = base + k;
+                E.FC[pool + leaf] = base;
+                const uint32_t flags = (prior_sum > 0) ? 0u : FLAG_UNIFORM64;
+                E.IN[pool + leaf] = (E.IN[pool + leaf] & 0xFF) | ((uint32_t)k << 8) | (flags << 16);
+            }
+        }
+    }
+}
+
+// _backpropagate (src/mcts.py:337-342): v is seen by the side to move at the leaf
+__device__ inline void dev_backup(const EngineView& E, int g, int lane, float v) {
+    const size_t pool = pool_base(E, g);
+    const int len = E.path_len[g];
+    const uint32_t* path = E.path + (size_t)g * MAX_DEPTH;
+    for (int i = lane; i < len; i += 64) {
+        const size_t n = pool + path[i];
+        const float vv = ((len - 1 - i) & 1) ? -v : v;   // value = -value per level
+        E.N[n] = E.N[n] + 1;
+        E.W[n] = E.W[n] + vv;
+    }
+    if (lane == 0) atomicAdd(E.stat_descents, 1ull);
+}
+
+}  // namespace az
