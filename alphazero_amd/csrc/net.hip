@@ -505,36 +505,61 @@ struct HeadParams {
     int B;
 };
 
+// A workgroup covers HEAD_MT x 16 positions and one K chunk; wave w owns NTW n-tiles.
+// Each weight fragment is used for HEAD_MT position tiles, which divides the L2 -> CU
+// weight traffic (the bound of this kernel) by HEAD_MT.
+constexpr int HEAD_MT = 1;
+
 template <int NTW, int NTILES>
 __device__ __forceinline__ void head_gemm_body(const __bf16* act, int K, const uint8_t* w, float* part,
                                                int N, int B, int chunk, int tile, int wave, int lane) {
     const int row = lane & 15, quarter = lane >> 4;
-    int pos = tile * 16 + row;
-    if (pos >= B) pos = B - 1;  // clamp loads; stores are masked below
-    const __bf16* arow = act + (size_t)pos * K + chunk * HEAD_KCHUNK + quarter * 8;
-    f32x4 acc[NTW];
+    const __bf16* arow[HEAD_MT];
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < HEAD_MT; ++m) {
+        int pos = (tile * HEAD_MT + m) * 16 + row;
+        if (pos >= B) pos = B - 1;  // clamp loads; stores are masked below
+        arow[m] = act + (size_t)pos * K + chunk * HEAD_KCHUNK + quarter * 8;
+    }
+    f32x4 acc[HEAD_MT][NTW];
+#pragma unroll
+    for (int m = 0; m < HEAD_MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int ks0 = chunk * (HEAD_KCHUNK / 32);
-#pragma unroll 4
-    for (int ks = 0; ks < HEAD_KCHUNK / 32; ++ks) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(arow + ks * 32);
+    const uint8_t* wbase = w + (((size_t)ks0 * NTILES + wave * NTW) * 64 + lane) * 16;
+    // latency-bound: keep HEAD_DEPTH k-steps of loads in flight before the MFMAs consume them
+    constexpr int HEAD_DEPTH = 8;
+    for (int ks0i = 0; ks0i < HEAD_KCHUNK / 32; ks0i += HEAD_DEPTH) {
+        bf16x8 a[HEAD_DEPTH][HEAD_MT], bb[HEAD_DEPTH][NTW];
+#pragma unroll
+        for (int d = 0; d < HEAD_DEPTH; ++d) {
+            const int ks = ks0i + d;
+#pragma unroll
+            for (int m = 0; m < HEAD_MT; ++m) a[d][m] = *reinterpret_cast<const bf16x8*>(arow[m] + ks * 32);
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+                bb[d][t] = *reinterpret_cast<const bf16x8*>(wbase + ((size_t)ks * NTILES + t) * 1024);
+        }
+#pragma unroll
+        for (int d = 0; d < HEAD_DEPTH; ++d)
+#pragma unroll
+            for (int m = 0; m < HEAD_MT; ++m)
+#pragma unroll
+                for (int t = 0; t < NTW; ++t)
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[d][m], bb[d][t], acc[m][t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int m = 0; m < HEAD_MT; ++m)
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
-            const int nt = wave * NTW + t;
-            const bf16x8 b = *reinterpret_cast<const bf16x8*>(w + (((size_t)(ks0 + ks) * NTILES + nt) * 64 + lane) * 16);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t], 0, 0, 0);
-        }
-    }
+            const int n = (wave * NTW + t) * 16 + (lane & 15);
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-        const int n = (wave * NTW + t) * 16 + (lane & 15);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int pp = tile * 16 + (lane >> 4) * 4 + v;
-            if (pp < B) part[((size_t)chunk * B + pp) * N + n] = acc[t][v];
+            for (int v = 0; v < 4; ++v) {
+                const int pp = (tile * HEAD_MT + m) * 16 + (lane >> 4) * 4 + v;
+                if (pp < B) part[((size_t)chunk * B + pp) * N + n] = acc[m][t][v];
+            }
         }
-    }
 }
 
 __global__ __launch_bounds__(256) void k_head_gemm(HeadParams p) {
@@ -853,7 +878,7 @@ int az::net_forward_partial(az_net* n, int32_t B, const uint64_t* mine_dev, cons
     hipLaunchKernelGGL(k_tower, dim3((B + 3) / 4), dim3(256), 0, s, tp);
     if (stamp) AZ_HIP(hipEventRecord(n->ev1[n->ev_used++], s));
     HeadParams hp{n->p_act, n->v_act, n->wp, n->wv, n->part_p, n->part_v, B};
-    hipLaunchKernelGGL(k_head_gemm, dim3((B + 15) / 16, POLICY_CHUNKS + VALUE_CHUNKS), dim3(256), 0, s, hp);
+    hipLaunchKernelGGL(k_head_gemm, dim3((B + 16 * HEAD_MT - 1) / (16 * HEAD_MT), POLICY_CHUNKS + VALUE_CHUNKS), dim3(256), 0, s, hp);
     AZ_HIP(hipGetLastError());
     return AZ_OK;
 }

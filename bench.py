@@ -191,6 +191,12 @@ def main():
 
     if rank == 0:
         flop_launch = tower_flop_per_position(args.blocks) * args.games
+        # HBM-side bytes per tower launch come from separate rocprofv3 --pmc passes
+        # (profiles/): counters cannot be read from inside this process
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_k_tower_pmc.json")
+        if os.path.exists(pmc) and args.games == 1024 and args.blocks == 20:
+            traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
         achieved = flop_launch / (tower_ms * 1e-3) if tower_ms > 0 else 0.0
         out = {
             "metric": "selfplay_mcts_simulations_per_sec",
@@ -212,7 +218,7 @@ def main():
                        "games_per_gpu": args.games, "sims_per_move": args.sims,
                        "parallelism": f"games sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_BF16_DENSE / 1e12,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_DENSE, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_DENSE, "traffic": traffic,
                          "kernel": "k_tower", "launch_ms": tower_ms, "launch_samples": tower_samples,
                          "flop_per_launch": flop_launch,
                          "mean_search_depth": eng.mean_depth()},
