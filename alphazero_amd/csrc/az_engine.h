@@ -43,6 +43,8 @@ struct EngineView {
     uint32_t* FC;
     uint32_t* IN;
     int32_t* err;
+    // per-game counters [B] (summed on the host when asked for: one shared counter would
+    // serialise 1024 atomics per simulation at the L2, ~12 us)
     unsigned long long *stat_depth, *stat_descents;
     unsigned long long *stat_terminal, *stat_rootexp;  // terminal leaves backed up, roots expanded
 };
@@ -143,6 +145,8 @@ struct az_engine {
 };
 
 namespace az {
+// tree.hip: sums of the per-game counters {depth, descents, terminal, rootexp}; synchronises
+int engine_counters(az_engine* e, unsigned long long out[4], hipStream_t s);
 // tree.hip: play the actions held in a device array (same as az_engine_advance)
 int advance_dev(az_engine* e, const int16_t* actions_dev, hipStream_t s);
 }  // namespace az

@@ -152,6 +152,7 @@ __global__ __launch_bounds__(64) void k_tree_step(EngineView E, FinishParams F, 
     if (!E.active[g]) return;
     const int need = E.leaf_need[g];
     float v = E.leaf_tv[g];
+    const SelectStart st = load_select_start(E, g);  // early: independent of everything below
     if (need) {
         float pr[3];
         v = dev_head_finish(F, g, lane, pr);
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(64) void k_tree_step(EngineView E, FinishParams F, 
     if (lane == 0) E.leaf_need[g] = 0;
     if (do_select) {
         __syncthreads();  // this wave's tree updates are visible to its own descent
-        dev_select(E, g, lane, nullptr, nullptr);
+        dev_select(E, g, lane, st, nullptr, nullptr);
     }
 }
 
@@ -296,12 +297,13 @@ extern "C" int az_engine_selfplay_stats(az_engine* e, az_selfplay_stats* out, vo
     unsigned long long st[4] = {0, 0, 0, 0}, sims = 0;
     uint32_t q = 0;
     AZ_HIP(hipMemcpyAsync(st, e->sp.stat, sizeof st, hipMemcpyDeviceToHost, s));
-    AZ_HIP(hipMemcpyAsync(&sims, e->v.stat_descents, sizeof sims, hipMemcpyDeviceToHost, s));
     AZ_HIP(hipMemcpyAsync(&q, e->sp.q_count, sizeof q, hipMemcpyDeviceToHost, s));
     AZ_HIP(hipStreamSynchronize(s));
-    unsigned long long term = 0, rootexp = 0;
-    AZ_HIP(hipMemcpy(&term, e->v.stat_terminal, sizeof term, hipMemcpyDeviceToHost));
-    AZ_HIP(hipMemcpy(&rootexp, e->v.stat_rootexp, sizeof rootexp, hipMemcpyDeviceToHost));
+    unsigned long long c[4];
+    const int rc = az::engine_counters(e, c, s);
+    if (rc != AZ_OK) return rc;
+    sims = c[1];
+    const unsigned long long term = c[2], rootexp = c[3];
     // every descent that did not end in a terminal leaf was evaluated, plus the root expansions
     out->simulations = sims; out->nn_evals = sims - term + rootexp; out->moves = st[0]; out->games_finished = st[1];
     out->samples_pending = q;

@@ -55,13 +55,18 @@ __global__ __launch_bounds__(64) void k_roots_prepare(EngineView E, float* plane
     }
     if (lane == 0) {
         E.leaf_need[g] = (uint8_t)need; if (need_eval) need_eval[g] = (uint8_t)need;
-        if (need) atomicAdd(E.stat_rootexp, 1ull);
+        if (need) E.stat_rootexp[g] += 1ull;
     }
 }
 
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_select(EngineView E, float* planes, uint8_t* need_eval) {
-    dev_select(E, blockIdx.x, threadIdx.x, planes, need_eval);
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (!E.active[g]) {
+        if (lane == 0) { E.leaf_need[g] = 0; if (need_eval) need_eval[g] = 0; }
+        return;
+    }
+    dev_select(E, g, lane, load_select_start(E, g), planes, need_eval);
 }
 
 __global__ __launch_bounds__(64) void k_expand_backup(EngineView E, const float* probs,
@@ -311,8 +316,8 @@ static int engine_alloc(az_engine* e) {
     AZ_ALLOC_RAW(V.N, 2 * B * cap); AZ_ALLOC_RAW(V.W, 2 * B * cap); AZ_ALLOC_RAW(V.P, 2 * B * cap);
     AZ_ALLOC_RAW(V.FC, 2 * B * cap); AZ_ALLOC_RAW(V.IN, 2 * B * cap);
 #undef AZ_ALLOC_RAW
-    AZ_ALLOC(V.err, 1); AZ_ALLOC(V.stat_depth, 1); AZ_ALLOC(V.stat_descents, 1);
-    AZ_ALLOC(V.stat_terminal, 1); AZ_ALLOC(V.stat_rootexp, 1);
+    AZ_ALLOC(V.err, 1); AZ_ALLOC(V.stat_depth, B); AZ_ALLOC(V.stat_descents, B);
+    AZ_ALLOC(V.stat_terminal, B); AZ_ALLOC(V.stat_rootexp, B);
     AZ_ALLOC(e->stage_slots, B); AZ_ALLOC(e->stage_w, B); AZ_ALLOC(e->stage_b, B);
     AZ_ALLOC(e->stage_t, B); AZ_ALLOC(e->stage_win, B); AZ_ALLOC(e->stage_act, B);
     AZ_ALLOC(e->stage_temps, B); AZ_ALLOC(e->query_dev, 1);
@@ -576,8 +581,25 @@ extern "C" int az_engine_stats(az_engine* e, uint64_t* depth_sum_host, uint64_t*
                                void* stream) {
     AZ_CHECK_ARG(e, "az_engine_stats: null engine");
     hipStream_t s = (hipStream_t)stream;
-    if (depth_sum_host) AZ_HIP(hipMemcpyAsync(depth_sum_host, e->v.stat_depth, 8, hipMemcpyDeviceToHost, s));
-    if (descents_host) AZ_HIP(hipMemcpyAsync(descents_host, e->v.stat_descents, 8, hipMemcpyDeviceToHost, s));
+    unsigned long long c[4];
+    const int rc = az::engine_counters(e, c, s);
+    if (rc != AZ_OK) return rc;
+    if (depth_sum_host) *depth_sum_host = c[0];
+    if (descents_host) *descents_host = c[1];
+    return AZ_OK;
+}
+
+int az::engine_counters(az_engine* e, unsigned long long out[4], hipStream_t s) {
+    const size_t B = e->v.B;
+    std::vector<unsigned long long> host(4 * B);
+    const unsigned long long* src[4] = {e->v.stat_depth, e->v.stat_descents, e->v.stat_terminal, e->v.stat_rootexp};
+    for (int i = 0; i < 4; ++i)
+        AZ_HIP(hipMemcpyAsync(host.data() + i * B, src[i], B * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     AZ_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < 4; ++i) {
+        unsigned long long t = 0;
+        for (size_t g = 0; g < B; ++g) t += host[i * B + g];
+        out[i] = t;
+    }
     return AZ_OK;
 }

@@ -53,43 +53,52 @@ __device__ inline double wave_sum_f64(double v) {
 
 // ---------------------------------------------------------------------------
 // One PUCT descent of game g by one wave: src/mcts.py:153-171 with _select_child (:281-312)
-__device__ inline void dev_select(const EngineView& E, int g, int lane, float* planes, uint8_t* need_eval) {
-    if (!E.active[g]) {
-        if (lane == 0) { E.leaf_need[g] = 0; if (need_eval) need_eval[g] = 0; }
-        return;
-    }
+// Per-game values the descent starts from; loading them early (before other work of
+// the same kernel) takes their latency off the critical path.
+struct SelectStart {
+    uint32_t root;
+    int rmode, turn, winner;
+    uint64_t white, black;
+};
+
+__device__ inline SelectStart load_select_start(const EngineView& E, int g) {
+    SelectStart s;
+    s.root = E.root[g]; s.rmode = E.root_mode[g]; s.turn = E.turn[g]; s.winner = E.winner[g];
+    s.white = E.white[g]; s.black = E.black[g];
+    return s;
+}
+
+// The caller has checked E.active[g].  Each level costs ONE round of dependent loads:
+// a node's own (info, first child, visits) arrive with its parent's child statistics.
+__device__ inline void dev_select(const EngineView& E, int g, int lane, const SelectStart& st,
+                                  float* planes, uint8_t* need_eval) {
     const size_t pool = pool_base(E, g);
-    const uint32_t r = E.root[g];
-    const int rmode = E.root_mode[g];
-    int t = E.turn[g];
-    int win = E.winner[g];
-    uint64_t mine, theirs;
-    {
-        const uint64_t w = E.white[g], b = E.black[g];
-        mine = (t > 0) ? w : bitrev64(b);
-        theirs = (t > 0) ? b : bitrev64(w);
-    }
+    const uint32_t r = st.root;
+    const int rmode = st.rmode;
+    int t = st.turn;
+    int win = st.winner;
+    uint64_t mine = (t > 0) ? st.white : bitrev64(st.black);
+    uint64_t theirs = (t > 0) ? st.black : bitrev64(st.white);
     uint32_t node = r;
     uint32_t* path = E.path + (size_t)g * MAX_DEPTH;
     int depth = 1;
     if (lane == 0) path[0] = node;
     const float cp32 = (float)E.c_puct;
+    uint32_t inf = E.IN[pool + node], fc = E.FC[pool + node], pn = E.N[pool + node];
     while (true) {
-        const uint32_t inf = E.IN[pool + node];
         const int k = (inf >> 8) & 0xFF;
         if (k == 0) break;
         if (depth >= MAX_DEPTH) { if (lane == 0) atomicOr(E.err, ERR_DEPTH); break; }
-        const uint32_t fc = E.FC[pool + node];
-        const uint32_t pn = E.N[pool + node];
         const double sqrt_parent = sqrt((double)(pn > 1 ? pn : 1));
         const bool root64 = (node == r) && rmode;
         const bool f64mode = root64 || ((inf >> 16) & FLAG_UNIFORM64);
         double score = -INFINITY;
-        uint32_t cinfo = 0;
+        uint32_t cinfo = 0, cfc = 0, cN = 0;
         if (lane < k) {
-            const uint32_t cN = E.N[pool + fc + lane];
+            cN = E.N[pool + fc + lane];
             const float cW = E.W[pool + fc + lane];
             cinfo = E.IN[pool + fc + lane];
+            cfc = E.FC[pool + fc + lane];
             if (!f64mode) {
                 const float cP = E.P[pool + fc + lane];
                 const float q = (cN == 0) ? 0.0f : -(cW / (float)cN);
@@ -112,6 +121,8 @@ __device__ inline void dev_select(const EngineView& E, int g, int lane, float* p
         const unsigned long long tie = __ballot(score == best);
         const int bl = (tie == 0) ? 0 : (__ffsll((long long)tie) - 1);
         const int a = __shfl((int)(cinfo & 0xFF), bl);
+        inf = __shfl(cinfo, bl); pn = __shfl(cN, bl);
+        const uint32_t next_fc = __shfl(cfc, bl);
         // decode_action + step in canonical coordinates (src/game.py:257-278, 156-187)
         const int sq = a / 3, d = a - 3 * sq;
         const int to = sq + ((d == 0) ? 8 : ((d == 1) ? 7 : 9));
@@ -123,6 +134,7 @@ __device__ inline void dev_select(const EngineView& E, int g, int lane, float* p
         const uint64_t nm = bitrev64(theirs), nt = bitrev64(mine);
         mine = nm; theirs = nt; t = -t;
         node = fc + bl;
+        fc = next_fc;
         if (lane == 0) path[depth] = node;
         ++depth;
     }
@@ -135,8 +147,8 @@ __device__ inline void dev_select(const EngineView& E, int g, int lane, float* p
         // src/mcts.py:328-335: result seen by the side to move at the leaf
         E.leaf_tv[g] = (win != 0) ? ((win == t) ? 1.0f : -1.0f) : -1.0f;
         if (need_eval) need_eval[g] = terminal ? 0 : 1;
-        atomicAdd(E.stat_depth, (unsigned long long)(depth - 1));
-        if (terminal) atomicAdd(E.stat_terminal, 1ull);
+        E.stat_depth[g] += (unsigned long long)(depth - 1);
+        if (terminal) E.stat_terminal[g] += 1ull;
     }
     if (!terminal && planes) write_planes(planes + (size_t)g * 192, mine, theirs, lane);
 }
@@ -197,7 +209,7 @@ __device__ inline void dev_backup(const EngineView& E, int g, int lane, float v)
         E.N[n] = E.N[n] + 1;
         E.W[n] = E.W[n] + vv;
     }
-    if (lane == 0) atomicAdd(E.stat_descents, 1ull);
+    if (lane == 0) E.stat_descents[g] += 1ull;
 }
 
 }  // namespace az
