@@ -78,6 +78,7 @@ struct TowerParams {
     __bf16* p_act;              // [B][64 px][128 ch]
     __bf16* v_act;              // [B][64 px][32 ch]
     int dbg;                    // diagnostic ablation flags (AZ_TOWER_DBG), 0 in production
+    unsigned long long* stamps; // diagnostic: [workgroup][8] cycle sums {loop, conv1 epilogue, block epilogue, count, squeeze, fc1, fc2, final}; NULL in production
 };
 
 // two floats -> packed bf16 (round to nearest even) in ONE v_cvt_pk_bf16_f32: the
@@ -101,6 +102,22 @@ __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v) {
 }
 __device__ __forceinline__ float bf16_lo(uint32_t v) { return __uint_as_float(v << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t v) { return __uint_as_float(v & 0xFFFF0000u); }
+
+// value of lane (lane ^ D) for D in {1, 2, 4, 8}: DPP lane exchange inside a row of 16
+// (row_shr:n = lane i reads lane i-n, row_shl:n = lane i reads lane i+n; lanes whose source
+// falls outside the row, or whose bank is masked off, keep `old`)
+template <int CTRL, int BANK>
+__device__ __forceinline__ float dpp_update(float old, float src) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, 0xF, BANK, false));
+}
+__device__ __forceinline__ float lane_xor(float x, int d) {
+    switch (d) {
+        case 1: return dpp_update<0xB1, 0xF>(x, x);                                     // quad_perm [1,0,3,2]
+        case 2: return dpp_update<0x4E, 0xF>(x, x);                                     // quad_perm [2,3,0,1]
+        case 4: return dpp_update<0x114, 0xA>(dpp_update<0x104, 0x5>(x, x), x);          // shl:4 banks 0,2 | shr:4 banks 1,3
+        default: return dpp_update<0x118, 0xF>(dpp_update<0x108, 0xF>(x, x), x);         // shl:8 | shr:8
+    }
+}
 
 // orders this wave's LDS writes before its later LDS reads by other lanes
 __device__ __forceinline__ void wave_lds_sync() {
@@ -291,7 +308,9 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
     wait_weights();
     __syncthreads();  // tap 0 landed, zero row visible
 
+    unsigned long long t_loop = 0, t_ep1 = 0, t_ep2 = 0, t_sq = 0, t_f1 = 0, t_f2 = 0, t_fin = 0;
     for (int conv = 0; conv < nconv; ++conv) {
+        const unsigned long long ts0 = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
         // the accumulators start from the folded-BN bias of this conv (in LDS since the
         // previous conv), so no epilogue has to add it
         {
@@ -340,6 +359,7 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
                 }
             }
         }
+        const unsigned long long ts1 = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
         // Epilogue addresses are rebuilt from an opaque zero on every pass: left
         // loop-invariant, the compiler hoists dozens of them out of the conv loop and
         // spills them to scratch, and every reload then sits on the critical path.
@@ -371,32 +391,42 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
                 continue;
             }
             // Squeeze: per-channel mean of z (= acc, bias included) over the 64 pixels.  Per
-            // channel tile the 16 per-lane partial sums are reduce-scattered over the 32
-            // lanes of each half (16 shuffles per tile instead of 16 x 5).
+            // channel tile the 16 per-lane partial sums are reduce-scattered over the 16 lanes
+            // of a row with DPP lane exchanges (VALU rate, no LDS round trips), leaving lane
+            // (r & 15) with the row total of accumulator register r & 15; one cross-row
+            // exchange then adds the two rows of the half-wave.
+            {
+                float rowsum[4];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                f32x16 v = acc[nt][0] + acc[nt][1];  // a register vector: constant indices only
+                for (int nt = 0; nt < 4; ++nt) {
+                    f32x16 v = acc[nt][0] + acc[nt][1];  // a register vector: constant indices only
 #pragma unroll
-                for (int step = 0; step < 4; ++step) {
-                    const int half = 8 >> step, o = 16 >> step;
-                    const bool up = (r & o) != 0;
+                    for (int step = 0; step < 4; ++step) {
+                        const int half = 8 >> step;   // exchange distance in lanes == values kept
+                        const bool up = (r & half) != 0;
 #pragma unroll
-                    for (int i = 0; i < half; ++i) {
-                        float a = v[i], b = v[i + half];
-                        // opaque copy: otherwise the two selects below are rewritten as a
-                        // dynamically indexed vector read (a 16-way v_cndmask chain each)
-                        asm("" : "+v"(a));
-                        const float send = up ? a : b;
-                        const float keepv = up ? b : a;
-                        v[i] = keepv + __shfl_xor(send, o);
+                        for (int i = 0; i < half; ++i) {
+                            float a = v[i], bq = v[i + half];
+                            // opaque copy: otherwise the two selects below are rewritten as a
+                            // dynamically indexed vector read (a 16-way v_cndmask chain each)
+                            asm("" : "+v"(a));
+                            const float send = up ? a : bq;
+                            const float keepv = up ? bq : a;
+                            v[i] = keepv + lane_xor(send, half);
+                        }
                     }
+                    rowsum[nt] = v[0];
                 }
-                const float tot = v[0] + __shfl_xor(v[0], 1);
-                const int idx = r >> 1;  // accumulator register index this lane pair reduced
-                const int ch = nt * 32 + (idx >> 2) * 8 + h * 4 + (idx & 3);
-                if ((r & 1) == 0) scratch[ch] = tot * (1.0f / 64.0f);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const float tot = rowsum[nt] + __shfl_xor(rowsum[nt], 16);
+                    const int idx = r & 15;  // accumulator register index this lane reduced
+                    const int ch = nt * 32 + (idx >> 2) * 8 + h * 4 + (idx & 3);
+                    if (r < 16) scratch[ch] = tot * (1.0f / 64.0f);
+                }
             }
             wave_lds_sync();
+            const unsigned long long tsa = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
             // fc1 (128 -> 16) + ReLU: lane = (j = lane&15, quarter = lane>>4)
             {
                 const int j = lane & 15, q4 = lane >> 4;
@@ -414,28 +444,39 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
                 if (lane < 16) scratch[128 + lane] = y;  // hidden[16]
             }
             wave_lds_sync();
+            const unsigned long long tsb = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
             // fc2 (16 -> 256) from the transposed weights: this lane computes the gate
-            // and the shift of channels lane and lane + 64
+            // and the shift of channels lane and lane + 64.  All 68 LDS reads are issued
+            // before the first multiply so that their latency is paid once.
             {
                 f32x4 hid[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) hid[i] = *reinterpret_cast<const f32x4*>(scratch + 128 + i * 4);
+                const float* w2c = se + SE_OFF_W2 + lane;  // one base register, immediate offsets below
+                float wv[4][17];                            // [gate0, gate1, shift0, shift1][16 weights + bias]
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int jj = 0; jj < 17; ++jj) {        // row 16 of the image is the bias b2
+                        wv[m][jj] = w2c[jj * 256 + 64 * m];
+                        wv[2 + m][jj] = w2c[jj * 256 + CH + 64 * m];
+                    }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    const int c = lane + 64 * m;
-                    const float* w2c = se + SE_OFF_W2 + c;  // one base register, immediate offsets below
-                    float g = w2c[16 * 256], sh = w2c[16 * 256 + CH];  // b2 follows W2 in the image
+                    float g = wv[m][16], sh = wv[2 + m][16];
 #pragma unroll
                     for (int jj = 0; jj < 16; ++jj) {
-                        g += w2c[jj * 256] * hid[jj >> 2][jj & 3];
-                        sh += w2c[jj * 256 + CH] * hid[jj >> 2][jj & 3];
+                        g += wv[m][jj] * hid[jj >> 2][jj & 3];
+                        sh += wv[2 + m][jj] * hid[jj >> 2][jj & 3];
                     }
-                    g = 1.0f / (1.0f + __expf(-g));  // sigmoid
-                    scratch[160 + c] = g;
-                    scratch[160 + CH + c] = sh;
+                    g = __builtin_amdgcn_rcpf(1.0f + __expf(-g));  // sigmoid
+                    scratch[160 + lane + 64 * m] = g;
+                    scratch[160 + CH + lane + 64 * m] = sh;
                 }
             }
             wave_lds_sync();
+            const unsigned long long tsc = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
             // out = relu(acc * gate + shift' + residual)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
@@ -455,6 +496,10 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
                 }
             }
             store_act<true, true, false>(region, acc, nullptr, resid, r, h);
+            if (p.stamps) {
+                const unsigned long long tsd = __builtin_amdgcn_s_memtime();
+                t_sq += tsa - ts1; t_f1 += tsb - tsa; t_f2 += tsc - tsb; t_fin += tsd - tsc;
+            }
             if (conv == nconv - 2) {
                 // ---- value head conv 1x1 (128 -> 32) on the tower output, + bias, ReLU -> v_act
                 f32x16 va[2];
@@ -489,6 +534,16 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
                 }
             }
         }
+        if (p.stamps) {
+            const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+            t_loop += ts1 - ts0;
+            if (conv & 1) t_ep2 += ts2 - ts1; else t_ep1 += ts2 - ts1;
+        }
+    }
+    if (p.stamps && tid == 0) {
+        unsigned long long* o = p.stamps + blockIdx.x * 8;
+        o[0] = t_loop; o[1] = t_ep1; o[2] = t_ep2; o[3] = (unsigned long long)nconv;
+        o[4] = t_sq; o[5] = t_f1; o[6] = t_f2; o[7] = t_fin;
     }
 }
 
@@ -612,6 +667,7 @@ struct az_net {
     float *part_p = nullptr, *part_v = nullptr;
     uint64_t *bits_mine = nullptr, *bits_theirs = nullptr;
     int32_t* bad = nullptr;
+    unsigned long long* stamps = nullptr;  // diagnostic cycle stamps (AZ_TOWER_STAMPS=1)
     // optional HIP-event timing of the tower kernel (az_net_set_timing)
     bool timing = false;
     int64_t launches = 0;
@@ -634,6 +690,14 @@ static int dev_alloc(az_net* n, T*& ptr, size_t count) {
     AZ_HIP(hipMemset(p, 0, count * sizeof(T)));
     ptr = (T*)p;
     n->allocs.push_back(p);
+    return AZ_OK;
+}
+
+// diagnostic: copies the [workgroups][4] cycle stamps of the last tower launch
+extern "C" int az_net_debug_stamps(az_net* n, unsigned long long* out_host, int32_t workgroups) {
+    AZ_CHECK_ARG(n && n->stamps && out_host, "az_net_debug_stamps: stamps are off (set AZ_TOWER_STAMPS=1 before az_net_create)");
+    AZ_HIP(hipDeviceSynchronize());
+    AZ_HIP(hipMemcpy(out_host, n->stamps, (size_t)workgroups * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return AZ_OK;
 }
 
@@ -699,6 +763,7 @@ extern "C" int az_net_create(az_net** out, const az_net_config* cfg) {
     A(p_act, B * POLICY_K); A(v_act, B * VALUE_K);
     A(part_p, (size_t)POLICY_CHUNKS * B * NUM_ACTIONS); A(part_v, (size_t)VALUE_CHUNKS * B * 128);
     A(bits_mine, B); A(bits_theirs, B); A(bad, 1);
+    if (getenv("AZ_TOWER_STAMPS")) A(stamps, (B + 3) / 4 * 8);
 #undef A
     if (rc != AZ_OK) { az_net_destroy(n); return rc; }
     *out = n;
@@ -873,6 +938,7 @@ int az::net_forward_partial(az_net* n, int32_t B, const uint64_t* mine_dev, cons
     tp.value_w = n->value_w; tp.value_b = n->value_b; tp.p_act = n->p_act; tp.v_act = n->v_act;
     static const int dbg = getenv("AZ_TOWER_DBG") ? atoi(getenv("AZ_TOWER_DBG")) : 0;
     tp.dbg = dbg;
+    tp.stamps = n->stamps;
     const bool stamp = n->timing && (n->launches++ % TIMING_STRIDE == 0) && n->ev_used < TIMING_POOL;
     if (stamp) AZ_HIP(hipEventRecord(n->ev0[n->ev_used], s));
     hipLaunchKernelGGL(k_tower, dim3((B + 3) / 4), dim3(256), 0, s, tp);
