@@ -151,6 +151,27 @@ __device__ __forceinline__ void glds4(const void* gsrc, uint32_t lds_dst) {
         : "v"(gsrc), "s"(lds_dst)
         : "memory");
 }
+// 8 KB: eight 64 x 16 B copies, 1 KB apart in both address spaces.  The instruction's
+// immediate offset is added to the global and to the LDS address alike, so one M0 value
+// and one address register serve all eight; both bases are passed 4 KB in (the
+// immediate is signed 13-bit).
+__device__ __forceinline__ void glds16x8(const void* gsrc_plus_4k, uint32_t lds_dst_plus_4k) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off offset:-4096\n\t"
+        "global_load_lds_dwordx4 %1, off offset:-3072\n\t"
+        "global_load_lds_dwordx4 %1, off offset:-2048\n\t"
+        "global_load_lds_dwordx4 %1, off offset:-1024\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+        "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+        "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc_plus_4k), "s"(lds_dst_plus_4k)
+        : "memory");
+}
 __device__ __forceinline__ void wait_weights() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 struct Frags {
@@ -234,8 +255,7 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
     auto prefetch = [&](int T) {
         const uint8_t* src = p.conv_w + (size_t)T * TAP_BYTES + wave_u * 8192 + lane * 16;
         const uint32_t dst = lds_base + LDS_W + (T & 1) * TAP_BYTES + wave_u * 8192;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) glds16(src + i * 1024, __builtin_amdgcn_readfirstlane(dst + i * 1024));
+        glds16x8(src + 4096, __builtin_amdgcn_readfirstlane(dst + 4096));
     };
     // folded-BN bias of conv c -> LDS bias buffer c&1 (waves 0 and 1, 256 B each)
     auto prefetch_bias = [&](int c) {
