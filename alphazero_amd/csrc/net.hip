@@ -78,7 +78,7 @@ struct TowerParams {
     __bf16* p_act;              // [B][64 px][128 ch]
     __bf16* v_act;              // [B][64 px][32 ch]
     int dbg;                    // diagnostic ablation flags (AZ_TOWER_DBG), 0 in production
-    unsigned long long* stamps; // diagnostic: [workgroup][8] cycle sums {loop, conv1 epilogue, block epilogue, count, squeeze, fc1, fc2, final}; NULL in production
+    unsigned long long* stamps; // diagnostic: [workgroup][10] cycle sums {loop, conv1 epilogue, block epilogue, 100 MHz ticks, squeeze, fc1, fc2, final, first tick, last tick}; NULL in production
 };
 
 // two floats -> packed bf16 (round to nearest even) in ONE v_cvt_pk_bf16_f32: the
@@ -329,6 +329,7 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
     __syncthreads();  // tap 0 landed, zero row visible
 
     unsigned long long t_loop = 0, t_ep1 = 0, t_ep2 = 0, t_sq = 0, t_f1 = 0, t_f2 = 0, t_fin = 0;
+    const unsigned long long rt0 = p.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
     for (int conv = 0; conv < nconv; ++conv) {
         const unsigned long long ts0 = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
         // the accumulators start from the folded-BN bias of this conv (in LDS since the
@@ -561,9 +562,10 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
         }
     }
     if (p.stamps && tid == 0) {
-        unsigned long long* o = p.stamps + blockIdx.x * 8;
-        o[0] = t_loop; o[1] = t_ep1; o[2] = t_ep2; o[3] = (unsigned long long)nconv;
+        unsigned long long* o = p.stamps + blockIdx.x * 10;
+        o[0] = t_loop; o[1] = t_ep1; o[2] = t_ep2; o[3] = __builtin_amdgcn_s_memrealtime() - rt0;  // 100 MHz ticks over the conv sequence
         o[4] = t_sq; o[5] = t_f1; o[6] = t_f2; o[7] = t_fin;
+        o[8] = rt0; o[9] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -713,11 +715,11 @@ static int dev_alloc(az_net* n, T*& ptr, size_t count) {
     return AZ_OK;
 }
 
-// diagnostic: copies the [workgroups][4] cycle stamps of the last tower launch
+// diagnostic: copies the [workgroups][10] cycle stamps of the last tower launch
 extern "C" int az_net_debug_stamps(az_net* n, unsigned long long* out_host, int32_t workgroups) {
     AZ_CHECK_ARG(n && n->stamps && out_host, "az_net_debug_stamps: stamps are off (set AZ_TOWER_STAMPS=1 before az_net_create)");
     AZ_HIP(hipDeviceSynchronize());
-    AZ_HIP(hipMemcpy(out_host, n->stamps, (size_t)workgroups * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    AZ_HIP(hipMemcpy(out_host, n->stamps, (size_t)workgroups * 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return AZ_OK;
 }
 
@@ -783,7 +785,7 @@ extern "C" int az_net_create(az_net** out, const az_net_config* cfg) {
     A(p_act, B * POLICY_K); A(v_act, B * VALUE_K);
     A(part_p, (size_t)POLICY_CHUNKS * B * NUM_ACTIONS); A(part_v, (size_t)VALUE_CHUNKS * B * 128);
     A(bits_mine, B); A(bits_theirs, B); A(bad, 1);
-    if (getenv("AZ_TOWER_STAMPS")) A(stamps, (B + 3) / 4 * 8);
+    if (getenv("AZ_TOWER_STAMPS")) A(stamps, (B + 3) / 4 * 10);
 #undef A
     if (rc != AZ_OK) { az_net_destroy(n); return rc; }
     *out = n;

@@ -38,15 +38,19 @@ if __name__ == "__main__":
         import numpy as np
         from alphazero_amd import _lib
         wg = (a.batch + 3) // 4
-        buf = np.zeros((wg, 8), np.uint64)
+        buf = np.zeros((wg, 10), np.uint64)
         L = _lib.lib()
         L.az_net_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         _lib.check(L.az_net_debug_stamps(inf.h, buf.ctypes.data_as(C.c_void_p), wg))
         m = buf.astype(np.float64).mean(0)
         tot = m[0] + m[1] + m[2]
+        ticks, m[3] = m[3], a.blocks * 2 + 1
         print(f"stamps (cycles per workgroup, mean): conv loops {m[0]:.0f} ({m[0]/tot*100:.1f}%), conv1 epilogues {m[1]:.0f} "
               f"({m[1]/tot*100:.1f}%), block epilogues {m[2]:.0f} ({m[2]/tot*100:.1f}%); per conv loop {m[0]/m[3]:.0f}, "
               f"per conv1 epilogue {m[1]/((m[3]+1)/2):.0f}, per block epilogue {m[2]/((m[3]-1)/2):.0f}; "
               f"block epilogue parts per block: squeeze {m[4]/((m[3]-1)/2):.0f}, fc1 {m[5]/((m[3]-1)/2):.0f}, "
-              f"fc2 {m[6]/((m[3]-1)/2):.0f}, scale+residual+store {m[7]/((m[3]-1)/2):.0f}")
+              f"fc2 {m[6]/((m[3]-1)/2):.0f}, scale+residual+store {m[7]/((m[3]-1)/2):.0f}; "
+              f"workgroup duration min/mean/max {buf[:,3].min()/100:.1f}/{ticks/100:.1f}/{buf[:,3].max()/100:.1f} us, "
+              f"first start to last end {(int(buf[:,9].max()) - int(buf[:,8].min()))/100:.1f} us, start skew {(int(buf[:,8].max()) - int(buf[:,8].min()))/100:.1f} us; "
+              f"stamp counter rate {tot / (ticks / 100e6) / 1e9:.3f} GHz over {ticks / 100:.1f} us")
     print(f"batch {a.batch} blocks {a.blocks}: {ms:.3f} ms/forward, {a.batch / ms * 1e3:.0f} pos/s, ~{tf:.1f} TFLOP/s")
