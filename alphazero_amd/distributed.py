@@ -87,14 +87,22 @@ def losses(model, states, target_pis, target_wls):
 
 def train_step(model, optimizer, states, target_pis, target_wls, group=None):
     """One optimisation step on this rank's slice of the batch; gradients are
-    averaged over the ranks of `group` when torch.distributed is initialised."""
+    averaged over the ranks of `group` when torch.distributed is initialised.  A
+    rank whose slice is empty (ragged last batch) contributes zero gradients and
+    still joins the all-reduce."""
     model.train()
-    loss, loss_pi, loss_wl = losses(model, states, target_pis, target_wls)
     optimizer.zero_grad()
-    loss.backward()
+    if states.shape[0] > 0:
+        loss, loss_pi, loss_wl = losses(model, states, target_pis, target_wls)
+        loss.backward()
+        out = (float(loss.detach()), float(loss_pi.detach()), float(loss_wl.detach()))
+    else:
+        for p in model.parameters():
+            p.grad = torch.zeros_like(p)
+        out = (0.0, 0.0, 0.0)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         allreduce_mean_gradients(model, group)
     if Config.GRAD_CLIP_NORM > 0:
         torch.nn.utils.clip_grad_norm_(model.parameters(), Config.GRAD_CLIP_NORM)
     optimizer.step()
-    return float(loss.detach()), float(loss_pi.detach()), float(loss_wl.detach())
+    return out

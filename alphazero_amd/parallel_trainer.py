@@ -1,0 +1,384 @@
+"""Drop-in for the reference's src/parallel_trainer.py: self-play driver, replay
+buffer, training step and the two on-disk formats.
+
+What differs from the reference in structure (results are the same):
+
+  * examples are held as three contiguous float32 arrays (`ExampleArrays`, a
+    sequence of (state, policy, wl) tuples to its users) instead of a Python
+    list of small arrays; in `learn()` they are uploaded to the training device
+    once and every batch is an index gather there, the mirror augmentation
+    (src/parallel_trainer.py:33-70) being a column flip and a fixed permutation
+    of the 192 policy entries applied to the rows that ask for it;
+  * batch order comes from torch's own DataLoader over the index range
+    [0, 2n), which draws from the global torch RNG exactly as the reference's
+    DataLoader over GameDataset does (:231-232), so a seeded run visits the
+    same examples in the same order;
+  * `execute_parallel_episodes` runs on the device engine (libazamd): fused
+    search + move choice + sample queue when the model is an AlphaZeroNet the
+    HIP inference supports, otherwise the reference's host loop over the
+    drop-in MCTS with any duck-typed model.
+"""
+import glob
+import os
+import re
+from typing import Iterable, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.optim as optim
+from torch.optim.lr_scheduler import CosineAnnealingLR
+from torch.utils.data import DataLoader, Dataset
+
+from .config import Config
+from .game import BOARD_SIZE, NUM_ACTIONS, WHITE, BreakthroughGame
+from .mcts import MCTS, Node
+from .model import AlphaZeroNet
+
+
+def _mirror_permutation() -> np.ndarray:
+    """perm with mirrored_policy = policy[perm]: the source square is the column
+    mirror of the target square, forward stays forward and the two diagonals
+    trade places (src/parallel_trainer.py:56-67).  It is its own inverse."""
+    perm = np.empty(NUM_ACTIONS, np.int64)
+    swap = (0, 2, 1)
+    for target in range(NUM_ACTIONS):
+        sq, d = divmod(target, 3)
+        row, col = divmod(sq, BOARD_SIZE)
+        perm[target] = (row * BOARD_SIZE + (BOARD_SIZE - 1 - col)) * 3 + swap[d]
+    return perm
+
+
+MIRROR_PERM = _mirror_permutation()
+
+
+def augment_example(state: np.ndarray, policy: np.ndarray, wl: np.ndarray) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Left-right mirror of one example (src/parallel_trainer.py:33-70): planes
+    flipped along the column axis, policy permuted, wl unchanged."""
+    return np.ascontiguousarray(state[:, :, ::-1]), policy[MIRROR_PERM], wl
+
+
+class ExampleArrays:
+    """n training examples as arrays states[n,3,8,8], policies[n,192], wls[n,2]
+    (the layout of training_data.npz) that reads like the reference's list of
+    (state, policy, wl) tuples: len, indexing, slicing, iteration, +."""
+
+    __slots__ = ("states", "policies", "wls")
+
+    def __init__(self, states=None, policies=None, wls=None):
+        self.states = np.zeros((0, 3, BOARD_SIZE, BOARD_SIZE), np.float32) if states is None else np.asarray(states, np.float32)
+        self.policies = np.zeros((0, NUM_ACTIONS), np.float32) if policies is None else np.asarray(policies, np.float32)
+        self.wls = np.zeros((0, 2), np.float32) if wls is None else np.asarray(wls, np.float32)
+        if not (len(self.states) == len(self.policies) == len(self.wls)):
+            raise ValueError("states, policies and wls must have the same length")
+
+    @classmethod
+    def of(cls, examples) -> "ExampleArrays":
+        if isinstance(examples, ExampleArrays):
+            return examples
+        examples = list(examples)
+        if not examples:
+            return cls()
+        return cls(np.stack([e[0] for e in examples]), np.stack([e[1] for e in examples]),
+                   np.stack([e[2] for e in examples]))
+
+    def __len__(self):
+        return len(self.states)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return ExampleArrays(self.states[i], self.policies[i], self.wls[i])
+        return self.states[i], self.policies[i], self.wls[i]
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+    def __add__(self, other):
+        return ExampleArrays.concat([self, ExampleArrays.of(other)])
+
+    def extend(self, other):
+        merged = self + other
+        self.states, self.policies, self.wls = merged.states, merged.policies, merged.wls
+
+    @staticmethod
+    def concat(parts: Iterable["ExampleArrays"]) -> "ExampleArrays":
+        parts = [p for p in parts if len(p)]
+        if not parts:
+            return ExampleArrays()
+        if len(parts) == 1:
+            return parts[0]
+        return ExampleArrays(np.concatenate([p.states for p in parts]), np.concatenate([p.policies for p in parts]),
+                             np.concatenate([p.wls for p in parts]))
+
+
+class GameDataset(Dataset):
+    """Examples followed by their mirrored copies (src/parallel_trainer.py:73-98)."""
+
+    def __init__(self, examples, augment: bool = True):
+        self.examples = ExampleArrays.of(examples)
+        self.augment = augment
+
+    def __len__(self):
+        return len(self.examples) * (2 if self.augment else 1)
+
+    def __getitem__(self, idx):
+        n = len(self.examples)
+        if self.augment and idx >= n:
+            item = augment_example(*self.examples[idx - n])
+        else:
+            item = self.examples[idx]
+        return tuple(torch.tensor(np.ascontiguousarray(x), dtype=torch.float32) for x in item)
+
+
+def gather_batch(states, policies, wls, idx, mirror_perm):
+    """Rows idx of the augmented data set [examples ; mirrored examples] from
+    device-resident arrays; idx >= n addresses the mirrored copy of idx - n."""
+    n = states.shape[0]
+    mirrored = idx >= n
+    real = torch.where(mirrored, idx - n, idx)
+    s, p, w = states[real], policies[real], wls[real]
+    s = torch.where(mirrored[:, None, None, None], s.flip(3), s)
+    p = torch.where(mirrored[:, None], p[:, mirror_perm], p)
+    return s, p, w
+
+
+class ParallelTrainer:
+    """Same constructor, attributes and methods as the reference's trainer
+    (src/parallel_trainer.py:101-476).  `seed` (extra) seeds the device RNG of
+    the fused self-play path; `verbose` (extra) enables the progress prints."""
+
+    def __init__(self, model: AlphaZeroNet, device: str = "cpu",
+                 num_parallel_games: int = Config.PARALLEL_GAMES,
+                 num_simulations: int = Config.MCTS_SIMULATIONS,
+                 checkpoint_dir: str = Config.CHECKPOINT_DIR, seed: int = 0, verbose: bool = True):
+        self.model = model
+        self.device = device
+        self.num_parallel_games = num_parallel_games
+        self.num_simulations = num_simulations
+        self.optimizer = optim.Adam(model.parameters(), lr=Config.LEARNING_RATE, weight_decay=Config.WEIGHT_DECAY)
+        self.scheduler = CosineAnnealingLR(self.optimizer, T_max=Config.LR_SCHEDULER_T_MAX,
+                                           eta_min=Config.LR_SCHEDULER_ETA_MIN)
+        self.mcts = MCTS(model, num_simulations=num_simulations, device=device)
+        self._examples = ExampleArrays()
+        self.max_examples = Config.BUFFER_SIZE
+        self.checkpoint_dir = checkpoint_dir
+        self.seed = seed
+        self.verbose = verbose
+        self._selfplay = None          # fused device self-play, built on first use
+        self._weights_changed = False  # the HIP inference copy is stale
+        os.makedirs(self.checkpoint_dir, exist_ok=True)
+
+    # ------------------------------------------------------------------ replay buffer
+    @property
+    def examples(self) -> ExampleArrays:
+        return self._examples
+
+    @examples.setter
+    def examples(self, value):
+        self._examples = ExampleArrays.of(value)
+
+    def add_examples(self, new_examples):
+        """Append and keep the most recent `max_examples` (src/parallel_trainer.py:437-442)."""
+        merged = self._examples + new_examples
+        if len(merged) > self.max_examples:
+            merged = merged[len(merged) - self.max_examples:]
+        self._examples = merged
+
+    def _say(self, msg):
+        if self.verbose:
+            print(msg)
+
+    # ------------------------------------------------------------------ self-play
+    def _fused_ok(self) -> bool:
+        m = self.model
+        return (isinstance(m, AlphaZeroNet) and m.hip_supported() and str(self.device).startswith("cuda")
+                and type(self.mcts) is MCTS and self.mcts.model is m)
+
+    def execute_parallel_episodes(self, num_games: Optional[int] = None) -> ExampleArrays:
+        """num_games games from the start position to the end, tree reuse, root noise,
+        temperature 1 for the first TEMPERATURE_THRESHOLD plies then 0
+        (src/parallel_trainer.py:137-223).  Returns the (state, policy, wl) examples."""
+        if num_games is None:
+            num_games = self.num_parallel_games
+        if self._fused_ok():
+            from .selfplay import SelfPlay
+            sp = self._selfplay
+            if sp is None or sp.engine.n < num_games or sp.num_simulations != self.mcts.num_simulations:
+                sp = self._selfplay = SelfPlay(self.model, n_games=num_games,
+                                               num_simulations=self.mcts.num_simulations,
+                                               c_puct=self.mcts.c_puct, seed=self.seed,
+                                               device=torch.device(self.device).index)
+                self._weights_changed = False
+            if self._weights_changed:
+                sp.inference.refresh()
+                self._weights_changed = False
+            return ExampleArrays(*sp.execute_parallel_episodes(num_games))
+        return self._host_loop_episodes(num_games)
+
+    def _host_loop_episodes(self, num_games: int) -> ExampleArrays:
+        """The reference's loop itself, over the drop-in MCTS (device trees, model called
+        between tree kernels): exact replay of its numpy draws."""
+        games = [BreakthroughGame() for _ in range(num_games)]
+        roots: List[Optional[Node]] = [None] * num_games
+        history = [[] for _ in range(num_games)]
+        plies = [0] * num_games
+        active = list(range(num_games))
+        out_s, out_p, out_w = [], [], []
+        while active:
+            new_roots = self.mcts.search_batch([games[i] for i in active], [roots[i] for i in active], add_noise=True)
+            still = []
+            for i, root in zip(active, new_roots):
+                game = games[i]
+                temperature = 1.0 if plies[i] < Config.TEMPERATURE_THRESHOLD else 0.0
+                probs = self.mcts.get_action_probs(root, temperature=temperature)
+                history[i].append((game.get_encoded_state(), probs, game.turn))
+                action = int(np.random.choice(len(probs), p=probs))
+                game.step(game.decode_action(action))
+                plies[i] += 1
+                roots[i] = root.children[action] if action in root.children else None
+                if game.is_terminal():
+                    w, l = game.get_result()
+                    for s, p, turn in history[i]:
+                        out_s.append(s)
+                        out_p.append(p)
+                        out_w.append((w, l) if turn == WHITE else (l, w))
+                else:
+                    still.append(i)
+            active = still
+        if not out_s:
+            return ExampleArrays()
+        return ExampleArrays(np.stack(out_s), np.stack(out_p), np.array(out_w, np.float32))
+
+    # ------------------------------------------------------------------ training
+    def learn(self, epochs: int = 10, batch_size: int = 64):
+        """epochs passes over [examples ; mirrored examples] in shuffled batches:
+        soft-target policy cross-entropy + WL cross-entropy, gradient clipping, Adam;
+        one cosine-schedule step at the end (src/parallel_trainer.py:225-284).
+        With torch.distributed initialised every rank must hold the same buffer and
+        RNG state; each then trains on its slice of every batch and gradients are
+        averaged.  Returns the mean losses of the last epoch."""
+        from . import distributed as azdist
+        import torch.distributed as dist
+        n = len(self._examples)
+        if n == 0:
+            return None
+        dev = torch.device(self.device)
+        states = torch.from_numpy(self._examples.states).to(dev)
+        policies = torch.from_numpy(self._examples.policies).to(dev)
+        wls = torch.from_numpy(self._examples.wls).to(dev)
+        perm = torch.from_numpy(MIRROR_PERM).to(dev)
+        # same sampler, same draws from the global torch RNG as a DataLoader over the 2n examples
+        index_batches = DataLoader(torch.arange(2 * n), batch_size=batch_size, shuffle=True)
+        world, rank = 1, 0
+        if dist.is_available() and dist.is_initialized():
+            world, rank = dist.get_world_size(), dist.get_rank()
+        self._say(f"Training on {2 * n} examples (augmented), LR: {self.optimizer.param_groups[0]['lr']:.6f}")
+        stats = None
+        for _ in range(epochs):
+            tot = np.zeros(3)
+            count = 0
+            for idx in index_batches:
+                if world > 1:
+                    idx = idx[rank::world]
+                s, p, w = gather_batch(states, policies, wls, idx.to(dev), perm)
+                tot += azdist.train_step(self.model, self.optimizer, s, p, w)
+                count += 1
+            stats = dict(zip(("loss", "pi", "wl"), (tot / max(count, 1)).tolist()))
+        self.scheduler.step()
+        self._weights_changed = True
+        return stats
+
+    # ------------------------------------------------------------------ checkpoints
+    def _checkpoint_dict(self):
+        return {
+            "state_dict": self.model.state_dict(),
+            "optimizer": self.optimizer.state_dict(),
+            "scheduler": self.scheduler.state_dict(),
+            "config": {"num_blocks": self.model.num_blocks, "num_filters": self.model.num_filters},
+        }
+
+    def _restore(self, path):
+        # tensors, numbers, strings, lists and dicts only: the restricted loader reads it
+        ck = torch.load(path, map_location=self.device, weights_only=True)
+        self.model.load_state_dict(ck["state_dict"])
+        self.optimizer.load_state_dict(ck["optimizer"])
+        if "scheduler" in ck:
+            self.scheduler.load_state_dict(ck["scheduler"])
+            self.scheduler.T_max = Config.LR_SCHEDULER_T_MAX   # the code's horizon wins over the file's
+        self._weights_changed = True
+
+    def save_iteration_checkpoint(self, iteration: int):
+        """iteration_N.pt with keys state_dict / optimizer / scheduler / iteration / config
+        (src/parallel_trainer.py:290-311)."""
+        ck = self._checkpoint_dict()
+        ck["iteration"] = iteration
+        name = f"iteration_{iteration}.pt"
+        torch.save(ck, os.path.join(self.checkpoint_dir, name))
+        self._say(f"Checkpoint saved: {name}")
+
+    def load_iteration_checkpoint(self, iteration: int) -> bool:
+        name = f"iteration_{iteration}.pt"
+        path = os.path.join(self.checkpoint_dir, name)
+        if not os.path.exists(path):
+            self._say(f"No checkpoint found: {name}")
+            return False
+        self._restore(path)
+        self._say(f"Loaded checkpoint: {name}")
+        return True
+
+    def get_latest_iteration(self) -> int:
+        """Highest N among iteration_N.pt in the checkpoint directory, 0 if none."""
+        best = 0
+        for f in glob.glob(os.path.join(self.checkpoint_dir, "iteration_*.pt")):
+            m = re.search(r"iteration_(\d+)\.pt$", f)
+            if m:
+                best = max(best, int(m.group(1)))
+        return best
+
+    def save_checkpoint(self, filename: str = "checkpoint.pt"):
+        """Legacy single-file form (src/parallel_trainer.py:448-460)."""
+        path = os.path.join(self.checkpoint_dir, filename)
+        torch.save(self._checkpoint_dict(), path)
+        self._say(f"Checkpoint saved to {path}")
+
+    def load_checkpoint(self, filename: str = "checkpoint.pt"):
+        path = os.path.join(self.checkpoint_dir, filename)
+        if os.path.exists(path):
+            self._restore(path)
+            self._say(f"Checkpoint loaded from {path}")
+        else:
+            self._say(f"No checkpoint found at {path}")
+
+    # ------------------------------------------------------------------ training data file
+    def _get_data_file_path(self) -> str:
+        return os.path.join(self.checkpoint_dir, Config.DATA_FILE)
+
+    def append_training_data(self, new_examples):
+        """training_data.npz = arrays states / policies / wls of every example so far
+        (src/parallel_trainer.py:367-396)."""
+        new = ExampleArrays.of(new_examples)
+        if len(new) == 0:
+            return
+        path = self._get_data_file_path()
+        if os.path.exists(path):
+            with np.load(path) as old:
+                new = ExampleArrays(old["states"], old["policies"], old["wls"]) + new
+        np.savez(path, states=new.states, policies=new.policies, wls=new.wls)
+        self._say(f"Training data saved: {len(new)} total examples")
+
+    def load_training_data(self, max_examples: Optional[int] = None) -> int:
+        """The most recent max_examples of the data file become the replay buffer
+        (src/parallel_trainer.py:398-435)."""
+        if max_examples is None:
+            max_examples = self.max_examples
+        path = self._get_data_file_path()
+        if not os.path.exists(path):
+            self._say("No training data file found")
+            self._examples = ExampleArrays()
+            return 0
+        with np.load(path) as data:
+            total = len(data["states"])
+            start = max(0, total - max_examples)
+            self._examples = ExampleArrays(data["states"][start:], data["policies"][start:], data["wls"][start:])
+        self._say(f"Loaded {len(self._examples)} training examples (of {total} total on disk)")
+        return len(self._examples)

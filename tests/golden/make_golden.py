@@ -321,10 +321,80 @@ def make_nn_tier():
     print("nn tier done")
 
 
+# ------------------------------------------------------------------ training tier
+def train_examples(n=48, seed=5):
+    """Synthetic (state, policy, wl) tuples of the shapes the trainer stores."""
+    rs = np.random.RandomState(seed)
+    ex = []
+    for _ in range(n):
+        st = (rs.rand(3, 8, 8) > 0.6).astype(np.float32)
+        st[2] = 1.0
+        pol = rs.rand(192).astype(np.float32) ** 4
+        pol /= pol.sum()
+        wl = np.array([1.0, 0.0] if rs.rand() < 0.5 else [0.0, 1.0], np.float32)
+        ex.append((st, pol, wl))
+    return ex
+
+
+def structure(obj):
+    """JSON-able description of a checkpoint value: tensors become shape/dtype."""
+    if isinstance(obj, torch.Tensor):
+        return {"tensor": list(obj.shape), "dtype": str(obj.dtype)}
+    if isinstance(obj, dict):
+        return {str(k): structure(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [structure(v) for v in obj]
+    return obj
+
+
+def make_train_tier():
+    import json
+    out = {}
+    ex = train_examples()
+    # mirror augmentation (src/parallel_trainer.py:33-70)
+    aug = [ref_pt.augment_example(*e) for e in ex[:6]]
+    out["aug_states"] = np.array([a[0] for a in aug])
+    out["aug_policies"] = np.array([a[1] for a in aug])
+    out["aug_wls"] = np.array([a[2] for a in aug])
+    # learn(): 2 epochs x 6 batches of 16 over 96 augmented examples, then the scheduler step
+    tmp = tempfile.mkdtemp()
+    torch.manual_seed(123)
+    model = AlphaZeroNet(num_blocks=1, num_filters=8)
+    tr = ref_pt.ParallelTrainer(model, device="cpu", num_parallel_games=2, num_simulations=4, checkpoint_dir=tmp)
+    tr.add_examples(ex)
+    torch.manual_seed(7)
+    tr.learn(epochs=2, batch_size=16)
+    sd = model.state_dict()
+    out["learn_keys"] = np.array(list(sd.keys()))
+    out["learn_sums"] = np.array([float(v.double().sum()) for v in sd.values()], np.float64)
+    out["learn_abs_sums"] = np.array([float(v.double().abs().sum()) for v in sd.values()], np.float64)
+    out["learn_input_conv"] = sd["input_conv.weight"].numpy()
+    out["learn_value_fc2"] = sd["value_fc2.weight"].numpy()
+    out["learn_lr_after"] = np.array(tr.optimizer.param_groups[0]["lr"], np.float64)
+    # on-disk formats: iteration_N.pt (:290-311) and training_data.npz (:367-396)
+    tr.save_iteration_checkpoint(3)
+    ck = torch.load(os.path.join(tmp, "iteration_3.pt"), weights_only=True)
+    out["checkpoint_structure"] = np.array(json.dumps(structure(ck), sort_keys=True))
+    tr.append_training_data(ex[:10])
+    tr.append_training_data(ex[10:25])
+    d = np.load(os.path.join(tmp, "training_data.npz"))
+    out["data_keys"] = np.array(sorted(d.files))
+    out["data_shapes"] = np.array(json.dumps({k: [list(d[k].shape), str(d[k].dtype)] for k in d.files}, sort_keys=True))
+    tr.max_examples = 12
+    n = tr.load_training_data()
+    out["data_loaded"] = np.array(n)
+    out["data_loaded_first_policy"] = tr.examples[0][1]
+    tr.add_examples(ex[25:30])
+    out["buffer_len_after_add"] = np.array(len(tr.examples))
+    out["buffer_first_policy_after_add"] = tr.examples[0][1]
+    out["latest_iteration"] = np.array(tr.get_latest_iteration())
+    np.savez_compressed(os.path.join(HERE, "train_tier.npz"), **out)
+    print("train tier done")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    make_table()
-    make_game_tier()
-    make_tree_tier()
-    make_selfplay_tier()
-    make_nn_tier()
+    tiers = {"table": make_table, "game": make_game_tier, "tree": make_tree_tier,
+             "selfplay": make_selfplay_tier, "nn": make_nn_tier, "train": make_train_tier}
+    for name in (sys.argv[1:] or list(tiers)):
+        tiers[name]()

@@ -76,6 +76,53 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
+def _learn_worker(rank, world, port, ret, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from alphazero_amd.model import AlphaZeroNet
+        from alphazero_amd.parallel_trainer import ParallelTrainer
+        torch.set_num_threads(1)
+        torch.manual_seed(0)
+        model = AlphaZeroNet(num_blocks=1, num_filters=8)
+        start = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
+        tr = ParallelTrainer(model, device="cpu", checkpoint_dir=os.path.join(tmp, f"r{rank}"), verbose=False)
+        rs = np.random.RandomState(1)                     # every rank holds the same replay buffer
+        n = 8
+        states = (rs.rand(n, 3, 8, 8) > 0.5).astype(np.float32)
+        pol = rs.rand(n, 192).astype(np.float32)
+        pol /= pol.sum(1, keepdims=True)
+        wls = np.tile(np.array([[1.0, 0.0], [0.0, 1.0]], np.float32), (n // 2, 1))
+        tr.add_examples(list(zip(states, pol, wls)))
+        torch.manual_seed(11)                             # and the same shuffle
+        # 16 augmented examples in batches of 5, 5, 5, 1: in the last one rank 1's slice is empty
+        stats = tr.learn(epochs=1, batch_size=5)
+        assert np.isfinite(stats["loss"])
+        flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+        assert not torch.equal(flat, start)
+        both = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        assert torch.equal(both[0], both[1])              # replicas stay identical
+        ret[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_learn_keeps_replicas_identical(tmp_path):
+    world = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_learn_worker, args=(r, world, port, ret, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert dict(ret) == {0: 1, 1: 1}
+
+
 def test_shard_games():
     assert [shard_games(8192, r, 8) for r in (0, 7)] == [(0, 1024), (7168, 8192)]
     spans = [shard_games(10, r, 4) for r in range(4)]
