@@ -74,6 +74,38 @@ def test_ragged_batch_sizes(B):
     _compare(model, _positions(B, seed=100 + B), min_top1=0.0 if B < 100 else 0.99)
 
 
+def test_batch_4096_full_network():
+    """The forward-only configuration (batch 4096, 20 x 128): tolerance against the float32
+    torch forward (run on the GPU for time, cross-checked against the CPU forward on a slice),
+    and independence of the batch composition (a position's outputs do not depend on its
+    neighbours: same bits at batch 4096 and in a batch of 1000)."""
+    from alphazero_amd.model import AlphaZeroNet, HipInference
+    torch.manual_seed(0)
+    model = AlphaZeroNet(num_blocks=20, num_filters=128)
+    randomize_bn(model, 1)
+    model.eval()
+    planes = _positions(4096, seed=77)
+    x = torch.from_numpy(planes)
+    with torch.no_grad():
+        pl_cpu, wl_cpu = model(x[:128])
+        gm = model.cuda()
+        pl, wl = (t.float().cpu() for t in gm(x.cuda()))
+        model.cpu()
+    assert float((pl[:128] - pl_cpu).abs().max()) < 1e-3 and float((wl[:128] - wl_cpu).abs().max()) < 1e-3
+    probs_ref = torch.softmax(pl, 1).numpy()
+    wlp = torch.softmax(wl, 1).numpy()
+    inf = HipInference(model, max_batch=4096)
+    probs, value, _, _ = inf.forward_planes(x.cuda())
+    probs, value = probs.cpu().numpy().copy(), value.cpu().numpy().copy()
+    assert np.abs(probs - probs_ref).max() <= TOL
+    assert np.abs(value - (wlp[:, 0] - wlp[:, 1])).max() <= TOL
+    assert (probs.argmax(1) == probs_ref.argmax(1)).mean() >= 0.99
+    sub = np.arange(3, 4096, 4)[:1000]
+    p2, v2, _, _ = inf.forward_planes(x[sub].contiguous().cuda())
+    assert np.array_equal(p2.cpu().numpy().view(np.uint32), probs[sub].view(np.uint32))
+    assert np.array_equal(v2.cpu().numpy().view(np.uint32), value[sub].view(np.uint32))
+
+
 def test_matches_reference_logits_fixture(golden_dir):
     """nn_tier.npz holds logits produced by the reference's own AlphaZeroNet
     (torch.manual_seed(0), 20 x 128, BatchNorm statistics randomised with seed 1)."""
