@@ -75,8 +75,11 @@ struct TowerParams {
     const uint8_t* se_img;      // [blocks][SE_BYTES] squeeze-excitation weights in their LDS image layout
     const uint8_t* value_w;     // [ks 8][lane 64][16 B]
     const float* value_b;       // [32]
-    __bf16* p_act;              // [B][64 px][128 ch]
-    __bf16* v_act;              // [B][64 px][32 ch]
+    // head activations, tiled for the head GEMM's fragment loads: position p, element k (k = px * C + ch)
+    // lives at ((p / 16 * (K / 32) + k / 32) * 16 + p % 16) * 32 + k % 32, so the 16 rows x 32 k of one
+    // MFMA A-fragment are one contiguous 1 KB block
+    __bf16* p_act;              // K = 64 px * 128 ch
+    __bf16* v_act;              // K = 64 px * 32 ch
     int dbg;                    // diagnostic ablation flags (AZ_TOWER_DBG), 0 in production
     unsigned long long* stamps; // diagnostic: [workgroup][10] cycle sums {loop, conv1 epilogue, block epilogue, 100 MHz ticks, squeeze, fc1, fc2, final, first tick, last tick}; NULL in production
 };
@@ -392,12 +395,13 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
             // ---- policy conv: + bias, ReLU -> LDS -> p_act (coalesced 16 B per lane)
             store_act<true, false, false>(region, acc, nullptr, resid, r, h);
             if (live) {
-                char* out = reinterpret_cast<char*>(p.p_act) + (size_t)pos * 64 * CH * 2;
+                // 64-byte pieces (one k-step of this position) at a 1 KB stride
+                char* out = reinterpret_cast<char*>(p.p_act) + (size_t)(pos >> 4) * (POLICY_K / 32) * 1024 + (pos & 15) * 64;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int idx = i * 64 + lane;  // 16-byte granule: pixel idx/16, part idx%16
                     const uint4 v = *reinterpret_cast<const uint4*>(region + (idx >> 4) * ACT_PITCH + (idx & 15) * 16);
-                    *reinterpret_cast<uint4*>(out + idx * 16) = v;
+                    *reinterpret_cast<uint4*>(out + (idx >> 2) * 1024 + (idx & 3) * 16) = v;
                 }
             }
         } else if ((conv & 1) == 0) {
@@ -537,7 +541,7 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
                     va[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x1, va[1], 0, 0, 0);
                 }
                 if (live) {
-                    char* out = reinterpret_cast<char*>(p.v_act) + (size_t)pos * 64 * VALUE_CH * 2;
+                    char* out = reinterpret_cast<char*>(p.v_act) + (size_t)(pos >> 4) * (VALUE_K / 32) * 1024 + (pos & 15) * 64;
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
                         const int ch0 = gq * 8 + h * 4;
@@ -548,7 +552,7 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
                             const float v1 = fmaxf(va[pt][gq * 4 + 1] + b[1], 0.f);
                             const float v2 = fmaxf(va[pt][gq * 4 + 2] + b[2], 0.f);
                             const float v3 = fmaxf(va[pt][gq * 4 + 3] + b[3], 0.f);
-                            *reinterpret_cast<uint2*>(out + ((pt * 32 + r) * VALUE_CH + ch0) * 2) =
+                            *reinterpret_cast<uint2*>(out + (pt * 32 + r) * 1024 + ch0 * 2) =   // k-step = pixel
                                 make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
                         }
                     }
@@ -573,8 +577,8 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
 // Head GEMMs: out_part[chunk][pos][N] = act[pos][chunk K-range] . W[n][same K-range]
 // v_mfma_f32_16x16x32_bf16, 16 positions per workgroup, wave w owns NTW n-tiles.
 struct HeadParams {
-    const __bf16* p_act;   // [B][8192]
-    const __bf16* v_act;   // [B][2048]
+    const __bf16* p_act;   // K = 8192, tiled as described at TowerParams
+    const __bf16* v_act;   // K = 2048
     const uint8_t* wp;     // policy FC, [kstep 256][ntile 12][lane 64][16 B]
     const uint8_t* wv;     // value FC1, [kstep 64][ntile 8][lane 64][16 B]
     float* part_p;         // [8][B][192]
@@ -594,9 +598,9 @@ __device__ __forceinline__ void head_gemm_body(const __bf16* act, int K, const u
     const __bf16* arow[HEAD_MT];
 #pragma unroll
     for (int m = 0; m < HEAD_MT; ++m) {
-        int pos = (tile * HEAD_MT + m) * 16 + row;
-        if (pos >= B) pos = B - 1;  // clamp loads; stores are masked below
-        arow[m] = act + (size_t)pos * K + chunk * HEAD_KCHUNK + quarter * 8;
+        // rows past B in the last tile hold stale data: an MFMA output row depends on its own
+        // input row only, and the stores below are masked
+        arow[m] = act + ((size_t)(tile * HEAD_MT + m) * (K / 32) + chunk * (HEAD_KCHUNK / 32)) * 512 + row * 32 + quarter * 8;
     }
     f32x4 acc[HEAD_MT][NTW];
 #pragma unroll
@@ -605,26 +609,32 @@ __device__ __forceinline__ void head_gemm_body(const __bf16* act, int K, const u
         for (int t = 0; t < NTW; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int ks0 = chunk * (HEAD_KCHUNK / 32);
     const uint8_t* wbase = w + (((size_t)ks0 * NTILES + wave * NTW) * 64 + lane) * 16;
-    // latency-bound: keep HEAD_DEPTH k-steps of loads in flight before the MFMAs consume them
-    constexpr int HEAD_DEPTH = 8;
-    for (int ks0i = 0; ks0i < HEAD_KCHUNK / 32; ks0i += HEAD_DEPTH) {
-        bf16x8 a[HEAD_DEPTH][HEAD_MT], bb[HEAD_DEPTH][NTW];
+    // latency-bound: two register sets of HEAD_DEPTH k-steps each, the loads of the next set in
+    // flight while the MFMAs consume the current one
+    constexpr int HEAD_DEPTH = 4, GROUPS = HEAD_KCHUNK / 32 / HEAD_DEPTH;
+    bf16x8 a[2][HEAD_DEPTH][HEAD_MT], bb[2][HEAD_DEPTH][NTW];
+    auto load_group = [&](int g, int set) {
 #pragma unroll
         for (int d = 0; d < HEAD_DEPTH; ++d) {
-            const int ks = ks0i + d;
+            const int ks = g * HEAD_DEPTH + d;
 #pragma unroll
-            for (int m = 0; m < HEAD_MT; ++m) a[d][m] = *reinterpret_cast<const bf16x8*>(arow[m] + ks * 32);
+            for (int m = 0; m < HEAD_MT; ++m) a[set][d][m] = *reinterpret_cast<const bf16x8*>(arow[m] + ks * 512);
 #pragma unroll
             for (int t = 0; t < NTW; ++t)
-                bb[d][t] = *reinterpret_cast<const bf16x8*>(wbase + ((size_t)ks * NTILES + t) * 1024);
+                bb[set][d][t] = *reinterpret_cast<const bf16x8*>(wbase + ((size_t)ks * NTILES + t) * 1024);
         }
+    };
+    load_group(0, 0);
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) {
+        if (g + 1 < GROUPS) load_group(g + 1, (g + 1) & 1);
 #pragma unroll
         for (int d = 0; d < HEAD_DEPTH; ++d)
 #pragma unroll
             for (int m = 0; m < HEAD_MT; ++m)
 #pragma unroll
                 for (int t = 0; t < NTW; ++t)
-                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[d][m], bb[d][t], acc[m][t], 0, 0, 0);
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[g & 1][d][m], bb[g & 1][d][t], acc[m][t], 0, 0, 0);
     }
 #pragma unroll
     for (int m = 0; m < HEAD_MT; ++m)
@@ -782,7 +792,7 @@ extern "C" int az_net_create(az_net** out, const az_net_config* cfg) {
     A(value_w, 8 * 64 * 16); A(value_b, VALUE_CH);
     A(wp, (size_t)(POLICY_K / 32) * 12 * 64 * 16); A(bp, NUM_ACTIONS);
     A(wv, (size_t)(VALUE_K / 32) * 8 * 64 * 16); A(bv1, 128); A(wv2, 256); A(bv2, 2);
-    A(p_act, B * POLICY_K); A(v_act, B * VALUE_K);
+    A(p_act, (size_t)((B + 15) / 16) * 16 * POLICY_K); A(v_act, (size_t)((B + 15) / 16) * 16 * VALUE_K);
     A(part_p, (size_t)POLICY_CHUNKS * B * NUM_ACTIONS); A(part_v, (size_t)VALUE_CHUNKS * B * 128);
     A(bits_mine, B); A(bits_theirs, B); A(bad, 1);
     if (getenv("AZ_TOWER_STAMPS")) A(stamps, (B + 3) / 4 * 10);
