@@ -10,7 +10,7 @@ namespace az {
 constexpr uint32_t NODE_NONE = 0xFFFFFFFFu;
 constexpr int MAX_DEPTH = 256;          // longest selection path (a game lasts < 200 plies)
 constexpr uint32_t FLAG_UNIFORM64 = 1;  // children hold the float64 prior 1/k (src/mcts.py:277-278)
-constexpr int ERR_POOL = 1, ERR_DEPTH = 2, ERR_HISTORY = 4;
+constexpr int ERR_POOL = 1, ERR_DEPTH = 2, ERR_HISTORY = 4, ERR_NODE = 8;
 
 // Device pointers + scalars, passed to kernels by value.
 struct EngineView {
@@ -135,6 +135,8 @@ struct az_engine {
     float* stage_temps = nullptr;
     az::NodeQuery* query_dev = nullptr;
     az::NodeQuery* query_host = nullptr;
+    az::NodeQuery* query_batch_dev = nullptr;    // [B], for az_engine_roots_children
+    az::NodeQuery* query_batch_host = nullptr;
     // fused self-play (selfplay.hip)
     struct az_net* net = nullptr;
     az::SelfplayView sp{};

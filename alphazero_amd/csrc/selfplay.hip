@@ -211,6 +211,7 @@ static int check_sticky(az_engine* e, hipStream_t s) {
     AZ_HIP(hipStreamSynchronize(s));
     if (flag & ERR_POOL) AZ_FAIL(AZ_ERR_CAPACITY, "node pool exhausted (pool_nodes_per_game = %u)", e->v.cap);
     if (flag & ERR_DEPTH) AZ_FAIL(AZ_ERR_CAPACITY, "selection path deeper than %d", MAX_DEPTH);
+    if (flag & ERR_NODE) AZ_FAIL(AZ_ERR_ARG, "az_engine_set_roots: a game slot or node index was out of range");
     if (flag & ERR_HISTORY) AZ_FAIL(AZ_ERR_CAPACITY, "sample queue or per-game history exhausted: drain samples more often");
     return AZ_OK;
 }

@@ -255,9 +255,18 @@ __global__ __launch_bounds__(64) void k_set_root(EngineView E, int g, int64_t no
     reroot_subtree(E, g, (uint32_t)node, lane);
 }
 
-__global__ __launch_bounds__(64) void k_node_children(EngineView E, int g, int64_t node_in,
-                                                      NodeQuery* out) {
+// batched form: block i re-roots game slots[i] at nodes[i] (negative: drop the tree)
+__global__ __launch_bounds__(64) void k_set_roots(EngineView E, int n, const int32_t* slots, const int64_t* nodes) {
     const int lane = threadIdx.x;
+    const int g = slots[blockIdx.x];
+    const int64_t node = nodes[blockIdx.x];
+    if (g < 0 || g >= E.B || node >= (int64_t)E.used[g]) { if (lane == 0) atomicOr(E.err, ERR_NODE); return; }
+    if (lane == 0) E.root_mode[g] = 0;
+    if (node < 0) { if (lane == 0) { E.root[g] = NODE_NONE; E.used[g] = 0; } return; }
+    reroot_subtree(E, g, (uint32_t)node, lane);
+}
+
+__device__ void node_query(const EngineView& E, int g, int64_t node_in, NodeQuery* out, int lane) {
     const size_t pool = pool_base(E, g);
     const uint32_t r = E.root[g];
     const uint32_t node = (node_in < 0) ? r : (uint32_t)node_in;
@@ -280,6 +289,16 @@ __global__ __launch_bounds__(64) void k_node_children(EngineView E, int g, int64
         out->prior_is64[lane] = (root64 || uni) ? 1 : 0;
         out->child_index[lane] = (int64_t)(fc + lane);
     }
+}
+
+__global__ __launch_bounds__(64) void k_node_children(EngineView E, int g, int64_t node_in,
+                                                      NodeQuery* out) {
+    node_query(E, g, node_in, out, threadIdx.x);
+}
+
+// block i reports the root of game slots[i]
+__global__ __launch_bounds__(64) void k_roots_children(EngineView E, const int32_t* slots, NodeQuery* out) {
+    node_query(E, slots[blockIdx.x], -1, out + blockIdx.x, threadIdx.x);
 }
 
 }  // namespace az
@@ -356,6 +375,7 @@ extern "C" int az_engine_destroy(az_engine* e) {
     if (!e) return AZ_OK;
     for (void* p : e->allocs) (void)hipFree(p);
     if (e->query_host) (void)hipHostFree(e->query_host);
+    if (e->query_batch_host) (void)hipHostFree(e->query_batch_host);
     delete e;
     return AZ_OK;
 }
@@ -366,6 +386,7 @@ static int check_err(az_engine* e, hipStream_t s) {
     AZ_HIP(hipStreamSynchronize(s));
     if (flag & ERR_POOL) AZ_FAIL(AZ_ERR_CAPACITY, "node pool exhausted (pool_nodes_per_game = %u)", e->v.cap);
     if (flag & ERR_DEPTH) AZ_FAIL(AZ_ERR_CAPACITY, "selection path deeper than %d", MAX_DEPTH);
+    if (flag & ERR_NODE) AZ_FAIL(AZ_ERR_ARG, "az_engine_set_roots: a game slot or node index was out of range");
     return AZ_OK;
 }
 
@@ -526,6 +547,50 @@ extern "C" int az_engine_node_children(az_engine* e, int32_t g, int64_t node, in
     return AZ_OK;
 }
 
+extern "C" int az_engine_roots_children(az_engine* e, int32_t n, const int32_t* slots_host, int32_t* k_host,
+                                        uint8_t* actions_host, uint32_t* visits_host, float* value_sum_host,
+                                        double* prior64_host, uint8_t* prior_is64_host,
+                                        int64_t* child_index_host, uint32_t* node_visits_host,
+                                        float* node_value_sum_host, int64_t* node_index_host, void* stream) {
+    AZ_CHECK_ARG(e && n >= 0 && n <= e->v.B, "az_engine_roots_children: n = %d out of range", n);
+    if (n == 0) return AZ_OK;
+    AZ_CHECK_ARG(slots_host, "az_engine_roots_children: null slots");
+    for (int i = 0; i < n; ++i)
+        AZ_CHECK_ARG(slots_host[i] >= 0 && slots_host[i] < e->v.B, "az_engine_roots_children: game %d out of range", slots_host[i]);
+    hipStream_t s = (hipStream_t)stream;
+    if (!e->query_batch_dev) {   // B records, allocated on first use
+        void* p = nullptr;
+        AZ_HIP(hipMalloc(&p, (size_t)e->v.B * sizeof(NodeQuery)));
+        e->allocs.push_back(p);
+        e->query_batch_dev = (NodeQuery*)p;
+        AZ_HIP(hipHostMalloc((void**)&e->query_batch_host, (size_t)e->v.B * sizeof(NodeQuery), hipHostMallocDefault));
+    }
+    AZ_HIP(hipMemcpyAsync(e->stage_slots, slots_host, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_roots_children, dim3(n), dim3(64), 0, s, e->v, e->stage_slots, e->query_batch_dev);
+    AZ_HIP(hipGetLastError());
+    AZ_HIP(hipMemcpyAsync(e->query_batch_host, e->query_batch_dev, (size_t)n * sizeof(NodeQuery), hipMemcpyDeviceToHost, s));
+    const int rc = check_err(e, s);  // synchronises
+    if (rc != AZ_OK) return rc;
+    for (int i = 0; i < n; ++i) {
+        const NodeQuery& q = e->query_batch_host[i];
+        const int k = q.k < 0 ? 0 : q.k;
+        if (k_host) k_host[i] = q.k;
+        if (node_visits_host) node_visits_host[i] = q.k < 0 ? 0 : q.node_visits;
+        if (node_value_sum_host) node_value_sum_host[i] = q.k < 0 ? 0.f : q.node_value_sum;
+        if (node_index_host) node_index_host[i] = q.node_index;
+        const size_t o = (size_t)i * MAX_CHILDREN;
+        for (int j = 0; j < k; ++j) {
+            if (actions_host) actions_host[o + j] = q.actions[j];
+            if (visits_host) visits_host[o + j] = q.visits[j];
+            if (value_sum_host) value_sum_host[o + j] = q.value_sum[j];
+            if (prior64_host) prior64_host[o + j] = q.prior64[j];
+            if (prior_is64_host) prior_is64_host[o + j] = q.prior_is64[j];
+            if (child_index_host) child_index_host[o + j] = q.child_index[j];
+        }
+    }
+    return AZ_OK;
+}
+
 extern "C" int az_engine_action_probs(az_engine* e, const float* temps_host, float* probs_dev,
                                       void* stream) {
     AZ_CHECK_ARG(e && probs_dev, "az_engine_action_probs: null argument");
@@ -567,6 +632,25 @@ extern "C" int az_engine_set_root(az_engine* e, int32_t g, int64_t node, void* s
     AZ_CHECK_ARG(node < (int64_t)e->v.cap, "az_engine_set_root: node out of range");
     hipLaunchKernelGGL(k_set_root, dim3(1), dim3(64), 0, (hipStream_t)stream, e->v, g, node);
     AZ_HIP(hipGetLastError());
+    return AZ_OK;
+}
+
+extern "C" int az_engine_set_roots(az_engine* e, int32_t n, const int32_t* slots_host, const int64_t* nodes_host,
+                                   void* stream) {
+    AZ_CHECK_ARG(e && n >= 0 && n <= e->v.B, "az_engine_set_roots: n = %d out of range", n);
+    if (n == 0) return AZ_OK;
+    AZ_CHECK_ARG(slots_host && nodes_host, "az_engine_set_roots: null array");
+    for (int i = 0; i < n; ++i) {
+        AZ_CHECK_ARG(slots_host[i] >= 0 && slots_host[i] < e->v.B, "az_engine_set_roots: game %d out of range", slots_host[i]);
+        AZ_CHECK_ARG(nodes_host[i] < (int64_t)e->v.cap, "az_engine_set_roots: node out of range");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    int64_t* nodes_dev = reinterpret_cast<int64_t*>(e->stage_w);
+    AZ_HIP(hipMemcpyAsync(e->stage_slots, slots_host, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    AZ_HIP(hipMemcpyAsync(nodes_dev, nodes_host, n * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_set_roots, dim3(n), dim3(64), 0, s, e->v, n, e->stage_slots, nodes_dev);
+    AZ_HIP(hipGetLastError());
+    AZ_HIP(hipStreamSynchronize(s));  // the staging buffers and host arrays are free again
     return AZ_OK;
 }
 

@@ -157,6 +157,34 @@ class Engine:
                     p_is64=is64[:kk].copy(), index=idx[:kk].copy(), root_N=int(nN.value),
                     root_W=float(nW.value), node=int(nidx.value))
 
+    def roots_children(self, slots):
+        """node_children of the roots of several games in one launch; a list of dicts
+        (None for a game without a root)."""
+        slots = np.ascontiguousarray(slots, np.int32)
+        n = len(slots)
+        k = np.zeros(n, np.int32)
+        act = np.zeros((n, 48), np.uint8)
+        N = np.zeros((n, 48), np.uint32)
+        W = np.zeros((n, 48), np.float32)
+        P = np.zeros((n, 48), np.float64)
+        is64 = np.zeros((n, 48), np.uint8)
+        idx = np.zeros((n, 48), np.int64)
+        nN = np.zeros(n, np.uint32)
+        nW = np.zeros(n, np.float32)
+        nidx = np.zeros(n, np.int64)
+        with torch.cuda.device(self.device):
+            check(_lib.lib().az_engine_roots_children(
+                self.h, n, _host_ptr(slots), _host_ptr(k), _host_ptr(act), _host_ptr(N), _host_ptr(W),
+                _host_ptr(P), _host_ptr(is64), _host_ptr(idx), _host_ptr(nN), _host_ptr(nW), _host_ptr(nidx),
+                _stream()))
+        out = []
+        for i in range(n):
+            kk = int(k[i])
+            out.append(None if kk < 0 else dict(
+                actions=act[i, :kk], N=N[i, :kk], W=W[i, :kk], P=P[i, :kk], p_is64=is64[i, :kk],
+                index=idx[i, :kk], root_N=int(nN[i]), root_W=float(nW[i]), node=int(nidx[i])))
+        return out
+
     def root_children(self, g):
         return self.node_children(g, -1)
 
@@ -174,6 +202,14 @@ class Engine:
 
     def set_root(self, g, node):
         check(_lib.lib().az_engine_set_root(self.h, int(g), int(node), _stream()))
+
+    def set_roots(self, slots, nodes):
+        """Re-root several games in one launch (slots[i] at pool node nodes[i])."""
+        slots = np.ascontiguousarray(slots, np.int32)
+        nodes = np.ascontiguousarray(nodes, np.int64)
+        assert len(slots) == len(nodes)
+        with torch.cuda.device(self.device):
+            check(_lib.lib().az_engine_set_roots(self.h, len(slots), _host_ptr(slots), _host_ptr(nodes), _stream()))
 
     def pool_usage(self):
         used = np.zeros(self.n, np.uint32)

@@ -83,7 +83,10 @@ class Node:
         t = self._tree
         if self._epoch != t.epoch:
             raise _lib.AzError("this Node belongs to a part of the tree that was dropped by a re-root")
-        q = t.engine.node_children(t.slot, self._idx)
+        self._fill(t.engine.node_children(t.slot, self._idx))
+
+    def _fill(self, q):
+        t = self._tree
         self._visit_count, self._value_sum, self._stats_loaded = q["root_N"], np.float32(q["root_W"]), True
         ch = {}
         for a, n, w, p, is64, idx in zip(q["actions"], q["N"], q["W"], q["P"], q["p_is64"], q["index"]):
@@ -290,16 +293,20 @@ class MCTS:
             engine.set_positions(slots[new], white[new], black[new], turn[new], winner[new])
         if (~new).any():
             engine.update_positions(slots[~new], white[~new], black[~new], turn[~new], winner[~new])
-        for r in roots:                       # re-root reused trees at the node that was passed in
+        move_slots, move_nodes = [], []       # re-root reused trees at the node that was passed in
+        for r in roots:
             t = r._tree
             if r._idx >= 0:
                 if r._epoch != t.epoch:
                     raise _lib.AzError("root Node belongs to a part of the tree that was dropped")
                 if r._idx != t.root_idx:
-                    engine.set_root(t.slot, r._idx)
+                    move_slots.append(t.slot)
+                    move_nodes.append(r._idx)
                     t.epoch += 1
                     t.root_idx = 0
                     r._idx, r._epoch = 0, t.epoch
+        if move_slots:
+            engine.set_roots(move_slots, move_nodes)
         active = np.zeros(engine.n, np.uint8)
         active[slots] = 1
         engine.set_active(active)
@@ -329,8 +336,13 @@ class MCTS:
                 engine.expand_backup(probs, values)
         engine.pool_usage()                   # surfaces a sticky capacity error
         engine.set_active(np.zeros(engine.n, np.uint8))
-        for r in roots:
+        # every returned root is read next (visit counts, children): one launch and one copy
+        # for all of them instead of one per handle
+        for r, q in zip(roots, engine.roots_children(slots)):
             t = r._tree
             if r._idx < 0:                    # the engine created the root at index 0 of the arena
                 r._idx, t.root_idx = 0, 0
-            r._invalidate()
+            if q is None:
+                r._invalidate()
+            else:
+                r._fill(q)

@@ -164,6 +164,16 @@ int az_engine_node_children(az_engine* e, int32_t g, int64_t node, int32_t* k_ho
                             int64_t* child_index_host, uint32_t* node_visits_host,
                             float* node_value_sum_host, int64_t* node_index_host, void* stream);
 
+/* The same for the roots of n games in one launch and one copy (what a caller
+ * of search_batch reads next from every returned root, src/parallel_trainer.py:182-196).
+ * Per-child outputs are [n][48], per-node outputs [n]; k_host[i] = -1 for a game
+ * without a root.  Synchronises the stream. */
+int az_engine_roots_children(az_engine* e, int32_t n, const int32_t* slots_host, int32_t* k_host,
+                             uint8_t* actions_host, uint32_t* visits_host, float* value_sum_host,
+                             double* prior64_host, uint8_t* prior_is64_host,
+                             int64_t* child_index_host, uint32_t* node_visits_host,
+                             float* node_value_sum_host, int64_t* node_index_host, void* stream);
+
 /* Number of children of every game's root (-1: no root), host array [B]. */
 int az_engine_root_counts(az_engine* e, int32_t* counts_host, void* stream);
 
@@ -179,6 +189,11 @@ int az_engine_advance(az_engine* e, const int16_t* actions_host, void* stream);
 /* Re-root game g at an arbitrary pool node without touching the position
  * (callers that pass Node handles back as roots). node = -1 drops the tree. */
 int az_engine_set_root(az_engine* e, int32_t g, int64_t node, void* stream);
+/* The same for n games in one launch: game slots_host[i] is re-rooted at
+ * nodes_host[i] (what search_batch does with a list of reused roots,
+ * src/mcts.py:117-125).  A slot may appear once.  A node index that is not in
+ * the game's tree is reported by the next call that checks the engine's error flag. */
+int az_engine_set_roots(az_engine* e, int32_t n, const int32_t* slots_host, const int64_t* nodes_host, void* stream);
 
 /* Diagnostics: nodes in use per game, sticky capacity-error flag. */
 int az_engine_pool_usage(az_engine* e, uint32_t* used_host, void* stream);

@@ -107,3 +107,41 @@ def test_many_games_vs_oracle():
             if orc.is_terminal(cpu.get_game(j)):
                 alive[j] = False
     assert abs(dev.mean_depth() - cpu.mean_depth()) < 1e-9
+
+
+def test_batched_root_queries_and_reroots_equal_single_calls():
+    """az_engine_roots_children / az_engine_set_roots against their one-game forms."""
+    from alphazero_amd._lib import AzError
+    from gpu_backend import EngineBackend
+    nG, S = 12, 60
+    ev = TableEvaluator()
+    a, b = EngineBackend(nG, pool_nodes_per_game=1 << 14), EngineBackend(nG, pool_nodes_per_game=1 << 14)
+    for be in (a, b):
+        for g in range(nG):
+            be.set_game(g, orc.start_position())
+        be.set_active(np.ones(nG, bool))
+        be.search(ev, S)
+    ea, eb = a.e, b.e
+    slots = np.array([7, 0, 11, 3], np.int32)
+    for q, g in zip(ea.roots_children(slots), slots):
+        one = ea.node_children(int(g))
+        for key in ("actions", "N", "W", "P", "p_is64", "index"):
+            assert np.array_equal(q[key], one[key]), key
+        assert (q["root_N"], q["root_W"], q["node"]) == (one["root_N"], one["root_W"], one["node"])
+    # re-root four games at their most visited child: batched on a, one by one on b
+    nodes = [int(ea.node_children(int(g))["index"][np.argmax(ea.node_children(int(g))["N"])]) for g in slots]
+    ea.set_roots(slots, nodes)
+    for g, nd in zip(slots, nodes):
+        eb.set_root(int(g), nd)
+    for g in range(nG):
+        qa, qb = ea.node_children(g), eb.node_children(g)
+        for key in ("actions", "N", "W", "P", "index"):
+            assert np.array_equal(qa[key], qb[key]), (g, key)
+        assert qa["root_N"] == qb["root_N"]
+    assert np.array_equal(ea.pool_usage(), eb.pool_usage())
+    # dropping a tree, and a node index outside the tree
+    ea.set_roots([5], [-1])
+    assert ea.roots_children([5])[0] is None
+    ea.set_roots([2], [int(ea.pool_usage()[2]) + 5])
+    with pytest.raises(AzError):
+        ea.pool_usage()
