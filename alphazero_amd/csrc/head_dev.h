@@ -33,17 +33,49 @@ __device__ __forceinline__ float head_wave_sum(float v) {
     return v;
 }
 
+// The global-memory operands of one position's head finish, held in registers so that a
+// caller can issue the loads long before it needs the result.
+struct HeadOperands {
+    float bp[3], part_p[3][POLICY_CHUNKS];
+    float bv1[2], part_v[2][VALUE_CHUNKS], wv2[2][2];
+    float bv2[2];
+};
+
+__device__ __forceinline__ HeadOperands head_load(const FinishParams& p, int pos, int lane) {
+    HeadOperands h;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int n = lane + 64 * i;
+        h.bp[i] = p.bp[n];
+#pragma unroll
+        for (int c = 0; c < POLICY_CHUNKS; ++c) h.part_p[i][c] = p.part_p[((size_t)c * p.B + pos) * NUM_ACTIONS + n];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int n = lane + 64 * i;
+        h.bv1[i] = p.bv1[n];
+#pragma unroll
+        for (int c = 0; c < VALUE_CHUNKS; ++c) h.part_v[i][c] = p.part_v[((size_t)c * p.B + pos) * 128 + n];
+        h.wv2[i][0] = p.wv2[n];
+        h.wv2[i][1] = p.wv2[128 + n];
+    }
+    h.bv2[0] = p.bv2[0];
+    h.bv2[1] = p.bv2[1];
+    return h;
+}
+
 // One wave per position.  probs_out[i] = probability of action lane + 64*i; returns
 // the value (identical in every lane).
-__device__ inline float dev_head_finish(const FinishParams& p, int pos, int lane, float (&probs_out)[3]) {
+__device__ __forceinline__ float head_compute(const FinishParams& p, const HeadOperands& h, int pos, int lane,
+                                              float (&probs_out)[3]) {
 #pragma clang fp contract(off)
     float lg[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int n = lane + 64 * i;
-        float s = p.bp[n];
+        float s = h.bp[i];
 #pragma unroll
-        for (int c = 0; c < POLICY_CHUNKS; ++c) s += p.part_p[((size_t)c * p.B + pos) * NUM_ACTIONS + n];
+        for (int c = 0; c < POLICY_CHUNKS; ++c) s += h.part_p[i][c];
         lg[i] = s;
         if (p.policy_logits) p.policy_logits[(size_t)pos * NUM_ACTIONS + n] = s;
     }
@@ -58,21 +90,25 @@ __device__ inline float dev_head_finish(const FinishParams& p, int pos, int lane
     float w0 = 0.f, w1 = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int n = lane + 64 * i;
-        float s = p.bv1[n];
+        float s = h.bv1[i];
 #pragma unroll
-        for (int c = 0; c < VALUE_CHUNKS; ++c) s += p.part_v[((size_t)c * p.B + pos) * 128 + n];
+        for (int c = 0; c < VALUE_CHUNKS; ++c) s += h.part_v[i][c];
         s = fmaxf(s, 0.f);
-        w0 += s * p.wv2[n];
-        w1 += s * p.wv2[128 + n];
+        w0 += s * h.wv2[i][0];
+        w1 += s * h.wv2[i][1];
     }
-    w0 = head_wave_sum(w0) + p.bv2[0];
-    w1 = head_wave_sum(w1) + p.bv2[1];
+    w0 = head_wave_sum(w0) + h.bv2[0];
+    w1 = head_wave_sum(w1) + h.bv2[1];
     if (lane == 0 && p.wl_logits) { p.wl_logits[2 * pos] = w0; p.wl_logits[2 * pos + 1] = w1; }
     const float m = fmaxf(w0, w1);
     const float e0 = __expf(w0 - m), e1 = __expf(w1 - m);
     const float is = 1.0f / (e0 + e1);
     return e0 * is - e1 * is;   // P(win) - P(loss), src/mcts.py:256
+}
+
+__device__ inline float dev_head_finish(const FinishParams& p, int pos, int lane, float (&probs_out)[3]) {
+    const HeadOperands h = head_load(p, pos, lane);
+    return head_compute(p, h, pos, lane, probs_out);
 }
 
 }  // namespace az

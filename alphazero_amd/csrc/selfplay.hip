@@ -144,28 +144,89 @@ __global__ void k_unpack_samples(SelfplayView S, uint32_t n, float* states, floa
 // One simulation's tree work for one game in ONE launch: finish the network heads for
 // the leaf (softmax / value), expand it, back the value up, then run the next
 // simulation's PUCT descent (src/mcts.py:153-187).
+//
+// The kernel is a chain of dependent memory round trips, so every load whose address is
+// known is issued up front, in three rounds: (1) the game's scalars, the recorded path and
+// the head partial sums; (2) the root's fields and the visit/value words of the path nodes;
+// (3) the root's child statistics.  Expansion and backup then only store, and the next
+// descent starts from registers patched with those stores; its first memory round trip
+// is the second tree level.
 __global__ __launch_bounds__(64) void k_tree_step(EngineView E, FinishParams F, int do_select) {
     __shared__ float s_probs[192];
     __shared__ float s_p[MAX_CHILDREN];
     __shared__ uint8_t s_a[MAX_CHILDREN];
     const int g = blockIdx.x, lane = threadIdx.x;
-    if (!E.active[g]) return;
+    // ---- round 1
+    const int active = E.active[g];
     const int need = E.leaf_need[g];
     float v = E.leaf_tv[g];
-    const SelectStart st = load_select_start(E, g);  // early: independent of everything below
+    const SelectStart st = load_select_start(E, g);
+    const size_t pool = pool_base(E, g);
+    const int len = E.path_len[g];
+    const uint32_t* path = E.path + (size_t)g * MAX_DEPTH;
+    const uint32_t my_path = path[lane];           // MAX_DEPTH >= 64: always in bounds
+    unsigned long long stat_descents = 0;
+    RootPrefetch pre;
+    pre.stat_depth = E.stat_depth[g]; pre.stat_terminal = E.stat_terminal[g];
+    if (lane == 0) stat_descents = E.stat_descents[g];
+    if (!active) return;
+    LeafState lf;
+    lf.node = E.leaf_node[g]; lf.mine = E.leaf_mine[g]; lf.theirs = E.leaf_theirs[g];
+    lf.turn = E.leaf_turn[g]; lf.used = E.used[g];
+    HeadOperands ho;
+    if (need) ho = head_load(F, g, lane);
+    // ---- round 2
+    const bool on_path = lane < len;
+    const size_t my_node = pool + (on_path ? my_path : st.root);
+    uint32_t bN = E.N[my_node];
+    float bW = E.W[my_node];
+    lf.info = E.IN[pool + lf.node];
+    pre.inf = E.IN[pool + st.root]; pre.fc = E.FC[pool + st.root];
+    // ---- round 3
+    const int rk = (pre.inf >> 8) & 0xFF;
+    if (do_select) pre.c = load_children(E, pool, g, pre.fc, rk, lane, st.rmode != 0);
+
+    Expansion ex{0, 0, lf.info};
     if (need) {
         float pr[3];
-        v = dev_head_finish(F, g, lane, pr);
+        v = head_compute(F, ho, g, lane, pr);
         s_probs[lane] = pr[0]; s_probs[lane + 64] = pr[1]; s_probs[lane + 128] = pr[2];
         __syncthreads();
-        dev_expand(E, g, lane, s_probs, s_p, s_a);
+        ex = dev_expand(E, g, lane, pool, lf, s_probs, s_p, s_a);
     }
-    dev_backup(E, g, lane, v);
-    if (lane == 0) E.leaf_need[g] = 0;
-    if (do_select) {
-        __syncthreads();  // this wave's tree updates are visible to its own descent
-        dev_select(E, g, lane, st, nullptr, nullptr);
+    // _backpropagate (src/mcts.py:337-342) on the preloaded words; deeper levels (rare) as usual
+    if (on_path) {
+        const float vv = ((len - 1 - lane) & 1) ? -v : v;
+        bN = bN + 1; bW = bW + vv;
+        E.N[my_node] = bN; E.W[my_node] = bW;
     }
+    for (int i = lane + 64; i < len; i += 64) {
+        const size_t n = pool + path[i];
+        const float vv = ((len - 1 - i) & 1) ? -v : v;
+        E.N[n] = E.N[n] + 1;
+        E.W[n] = E.W[n] + vv;
+    }
+    if (lane == 0) { E.stat_descents[g] = stat_descents + 1ull; E.leaf_need[g] = 0; }
+    if (!do_select) return;
+    __syncthreads();  // this wave's tree updates are visible to its own descent
+    if (len == 1) {
+        // the leaf was the root itself: its children did not exist when round 3 was issued
+        pre.inf = ex.info; pre.fc = ex.first; pre.pn = __shfl(bN, 0);
+        const int k = (pre.inf >> 8) & 0xFF;
+        pre.c = load_children(E, pool, g, pre.fc, k, lane, st.rmode != 0);
+    } else {
+        // patch the prefetched registers with what this launch stored: the root's visit, the
+        // visit and value of the root child on the path, and that child's expansion
+        pre.pn = __shfl(bN, 0);
+        const uint32_t child = __shfl(my_path, 1);
+        const uint32_t cN1 = __shfl(bN, 1);
+        const float cW1 = __shfl(bW, 1);
+        if (pre.fc + (uint32_t)lane == child) {
+            pre.c.cN = cN1; pre.c.cW = cW1;
+            if (len == 2 && ex.k > 0) { pre.c.cinfo = ex.info; pre.c.cfc = ex.first; }
+        }
+    }
+    dev_select(E, g, lane, st, nullptr, nullptr, &pre);
 }
 
 }  // namespace az

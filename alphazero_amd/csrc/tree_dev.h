@@ -68,10 +68,41 @@ __device__ inline SelectStart load_select_start(const EngineView& E, int g) {
     return s;
 }
 
+// Statistics of the children of one node as the descent reads them, one child per lane.
+struct ChildRegs {
+    uint32_t cN, cinfo, cfc;
+    float cW, cP;
+    double p64;      // noisy root prior (root_p64), only read for a root in float64 mode
+};
+
+// What a caller may load ahead of dev_select: the root's own fields, its children, and the
+// per-game counters the descent updates.  The caller patches these registers with the
+// tree updates it made after loading them.
+struct RootPrefetch {
+    uint32_t inf, fc, pn;
+    ChildRegs c;
+    unsigned long long stat_depth, stat_terminal;
+};
+
+__device__ inline ChildRegs load_children(const EngineView& E, size_t pool, int g, uint32_t fc, int k, int lane,
+                                          bool want_p64) {
+    ChildRegs c{0, 0, 0, 0.f, 0.f, 0.0};
+    if (lane < k) {
+        c.cN = E.N[pool + fc + lane];
+        c.cW = E.W[pool + fc + lane];
+        c.cinfo = E.IN[pool + fc + lane];
+        c.cfc = E.FC[pool + fc + lane];
+        c.cP = E.P[pool + fc + lane];
+        if (want_p64) c.p64 = E.root_p64[(size_t)g * 48 + lane];
+    }
+    return c;
+}
+
 // The caller has checked E.active[g].  Each level costs ONE round of dependent loads:
 // a node's own (info, first child, visits) arrive with its parent's child statistics.
+// With `pre` the root level costs none.
 __device__ inline void dev_select(const EngineView& E, int g, int lane, const SelectStart& st,
-                                  float* planes, uint8_t* need_eval) {
+                                  float* planes, uint8_t* need_eval, const RootPrefetch* pre = nullptr) {
     const size_t pool = pool_base(E, g);
     const uint32_t r = st.root;
     const int rmode = st.rmode;
@@ -84,7 +115,9 @@ __device__ inline void dev_select(const EngineView& E, int g, int lane, const Se
     int depth = 1;
     if (lane == 0) path[0] = node;
     const float cp32 = (float)E.c_puct;
-    uint32_t inf = E.IN[pool + node], fc = E.FC[pool + node], pn = E.N[pool + node];
+    uint32_t inf, fc, pn;
+    if (pre) { inf = pre->inf; fc = pre->fc; pn = pre->pn; }
+    else { inf = E.IN[pool + node]; fc = E.FC[pool + node]; pn = E.N[pool + node]; }
     while (true) {
         const int k = (inf >> 8) & 0xFF;
         if (k == 0) break;
@@ -93,14 +126,12 @@ __device__ inline void dev_select(const EngineView& E, int g, int lane, const Se
         const bool root64 = (node == r) && rmode;
         const bool f64mode = root64 || ((inf >> 16) & FLAG_UNIFORM64);
         double score = -INFINITY;
-        uint32_t cinfo = 0, cfc = 0, cN = 0;
+        const ChildRegs c = (pre && depth == 1) ? pre->c : load_children(E, pool, g, fc, k, lane, root64);
+        const uint32_t cinfo = c.cinfo, cfc = c.cfc, cN = c.cN;
         if (lane < k) {
-            cN = E.N[pool + fc + lane];
-            const float cW = E.W[pool + fc + lane];
-            cinfo = E.IN[pool + fc + lane];
-            cfc = E.FC[pool + fc + lane];
+            const float cW = c.cW;
             if (!f64mode) {
-                const float cP = E.P[pool + fc + lane];
+                const float cP = c.cP;
                 const float q = (cN == 0) ? 0.0f : -(cW / (float)cN);
                 float u = cp32 * cP;
                 u = u * (float)sqrt_parent;
@@ -108,7 +139,7 @@ __device__ inline void dev_select(const EngineView& E, int g, int lane, const Se
                 const float s = q + u;
                 score = (double)s;
             } else {
-                const double p64 = root64 ? E.root_p64[(size_t)g * 48 + lane] : 1.0 / (double)k;
+                const double p64 = root64 ? c.p64 : 1.0 / (double)k;
                 const double q = (cN == 0) ? 0.0 : (double)(-(cW / (float)cN));
                 double u = E.c_puct * p64;
                 u = u * sqrt_parent;
@@ -147,8 +178,9 @@ __device__ inline void dev_select(const EngineView& E, int g, int lane, const Se
         // src/mcts.py:328-335: result seen by the side to move at the leaf
         E.leaf_tv[g] = (win != 0) ? ((win == t) ? 1.0f : -1.0f) : -1.0f;
         if (need_eval) need_eval[g] = terminal ? 0 : 1;
-        E.stat_depth[g] += (unsigned long long)(depth - 1);
-        if (terminal) E.stat_terminal[g] += 1ull;
+        const unsigned long long sd = pre ? pre->stat_depth : E.stat_depth[g];
+        E.stat_depth[g] = sd + (unsigned long long)(depth - 1);
+        if (terminal) E.stat_terminal[g] = (pre ? pre->stat_terminal : E.stat_terminal[g]) + 1ull;
     }
     if (!terminal && planes) write_planes(planes + (size_t)g * 192, mine, theirs, lane);
 }
@@ -156,12 +188,34 @@ __device__ inline void dev_select(const EngineView& E, int g, int lane, const Se
 // ---------------------------------------------------------------------------
 // _expand_node (src/mcts.py:260-279).  pr: the 192 softmaxed policy values of this
 // leaf (global or LDS); s_p / s_a: 48-entry LDS scratch.  One wave, all lanes.
-__device__ inline void dev_expand(const EngineView& E, int g, int lane, const float* pr, float* s_p,
-                                  uint8_t* s_a) {
-    const size_t pool = pool_base(E, g);
-    const uint64_t mine = E.leaf_mine[g], theirs = E.leaf_theirs[g];
-    const int t = E.leaf_turn[g];
-    const uint32_t leaf = E.leaf_node[g];
+// The leaf a simulation stopped at, and what its expansion wrote into it.
+struct LeafState {
+    uint32_t node;
+    uint64_t mine, theirs;
+    int turn;
+    uint32_t used;       // E.used[g] before the expansion
+    uint32_t info;       // E.IN[leaf] before the expansion
+};
+struct Expansion {
+    int k;               // children created (0: none)
+    uint32_t first;      // pool index of the first one
+    uint32_t info;       // the leaf's new E.IN word
+};
+
+__device__ inline LeafState load_leaf(const EngineView& E, int g, size_t pool) {
+    LeafState s;
+    s.node = E.leaf_node[g]; s.mine = E.leaf_mine[g]; s.theirs = E.leaf_theirs[g];
+    s.turn = E.leaf_turn[g]; s.used = E.used[g];
+    s.info = E.IN[pool + s.node];
+    return s;
+}
+
+__device__ inline Expansion dev_expand(const EngineView& E, int g, int lane, size_t pool, const LeafState& lf,
+                                       const float* pr, float* s_p, uint8_t* s_a) {
+    const uint64_t mine = lf.mine, theirs = lf.theirs;
+    const int t = lf.turn;
+    const uint32_t leaf = lf.node;
+    Expansion ex{0, 0, lf.info};
     const Legal3 l = legal_sources(mine, theirs);
     const int k = __popcll(l.fwd) + __popcll(l.dl) + __popcll(l.dr);
     // insertion order (src/game.py:117-118 scans the REAL board row-major):
@@ -179,7 +233,7 @@ __device__ inline void dev_expand(const EngineView& E, int g, int lane, const fl
     float prior_sum = 0.0f;                       // sequential float32 sum, insertion order
     for (int i = 0; i < k; ++i) prior_sum = prior_sum + __shfl(p_r, i);
     if (k > 0) {
-        const uint32_t base = E.used[g];
+        const uint32_t base = lf.used;
         if ((uint64_t)base + (uint64_t)k > (uint64_t)E.cap) {
             if (lane == 0) atomicOr(E.err, ERR_POOL);
         } else {
@@ -188,14 +242,24 @@ __device__ inline void dev_expand(const EngineView& E, int g, int lane, const fl
                 E.N[c] = 0; E.W[c] = 0.f; E.FC[c] = 0; E.IN[c] = a_r;
                 E.P[c] = (prior_sum > 0) ? (p_r / prior_sum) : (float)(1.0 / (double)k);
             }
+            const uint32_t flags = (prior_sum > 0) ? 0u : FLAG_UNIFORM64;
+            ex.k = k; ex.first = base;
+            ex.info = (lf.info & 0xFF) | ((uint32_t)k << 8) | (flags << 16);
             if (lane == 0) {
                 E.used[g] = base + k;
                 E.FC[pool + leaf] = base;
-                const uint32_t flags = (prior_sum > 0) ? 0u : FLAG_UNIFORM64;
-                E.IN[pool + leaf] = (E.IN[pool + leaf] & 0xFF) | ((uint32_t)k << 8) | (flags << 16);
+                E.IN[pool + leaf] = ex.info;
             }
         }
     }
+    return ex;
+}
+
+__device__ inline void dev_expand(const EngineView& E, int g, int lane, const float* pr, float* s_p,
+                                  uint8_t* s_a) {
+    const size_t pool = pool_base(E, g);
+    const LeafState lf = load_leaf(E, g, pool);
+    (void)dev_expand(E, g, lane, pool, lf, pr, s_p, s_a);
 }
 
 // _backpropagate (src/mcts.py:337-342): v is seen by the side to move at the leaf
