@@ -574,6 +574,344 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
 }
 
 // ---------------------------------------------------------------------------
+// Small-batch form of the tower.  k_tower gives every wave a whole position, which
+// fills the chip only from 1024 positions up and makes the latency of one forward the
+// time one wave needs for all 41 convs.  Here the 128 output channels of a position are
+// split over 4 / NT waves (NT channel tiles of 32 per wave), a workgroup holds NT
+// positions, and a batch of B positions occupies B / NT compute units: NT = 1 up to 256
+// positions, NT = 2 up to 512.  Same weight images, same LDS layout (the activation
+// regions the workgroup does not need hold the squeeze-excitation scratch), same
+// arithmetic per output element; a workgroup barrier closes every epilogue because a
+// conv now reads channels written by other waves.
+template <int NT, bool RELU, bool KEEP>
+__device__ __forceinline__ void store_act_n(char* region, const f32x16 (&acc)[NT][2], uint32_t (&keep)[NT][2][8],
+                                            int r, int h, int nt0) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int ch0 = (nt0 + nt) * 32 + gq * 8 + h * 4;
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                uint32_t lo = pack_bf16x2(acc[nt][pt][gq * 4 + 0], acc[nt][pt][gq * 4 + 1]);
+                uint32_t hi = pack_bf16x2(acc[nt][pt][gq * 4 + 2], acc[nt][pt][gq * 4 + 3]);
+                if (RELU) { lo = relu_bf16x2(lo); hi = relu_bf16x2(hi); }
+                if (KEEP) { keep[nt][pt][gq * 2 + 0] = lo; keep[nt][pt][gq * 2 + 1] = hi; }
+                *reinterpret_cast<uint2*>(region + (pt * 32 + r) * ACT_PITCH + ch0 * 2) = make_uint2(lo, hi);
+            }
+        }
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256, 1) void k_tower_split(TowerParams p) {
+    constexpr int WPP = 4 / NT;  // waves per position
+    static_assert(NT == 1 || NT == 2, "a whole position per wave is k_tower");
+    __shared__ __attribute__((aligned(1024))) char lds[LDS_TOTAL];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int r = lane & 31, h = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lp = wave_u / WPP;            // position of this wave inside the workgroup
+    const int cw = wave_u % WPP;            // its channel group
+    const int nt0 = cw * NT;                // first channel tile of the group
+    const int pos = blockIdx.x * NT + lp;
+    const bool live = pos < p.B;
+    char* region = lds + lp * ACT_REGION;
+    // floats: [0,128) channel means, [128 + 16 cw, +16) hidden layer (per wave), [192,320) gates, [320,448) shifts
+    float* scratch = reinterpret_cast<float*>(lds + 3 * ACT_REGION + lp * 2048);
+    const int nconv = 2 * p.blocks + 1;
+    const int total_taps = nconv * 9;
+
+    for (int i = tid; i < 512 / 4; i += 256) reinterpret_cast<uint32_t*>(lds + LDS_ZERO)[i] = 0;
+
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_void*)lds;
+    // Weight taps: NT = 1 runs a tap in well under a microsecond, less than an L2 -> LDS copy
+    // takes, so it keeps three tap buffers (the third in an activation region it does not
+    // need) and copies two taps ahead; NT = 2 copies one tap ahead into two buffers.
+    constexpr int NBUF = (NT == 1) ? 3 : 2, AHEAD = NBUF - 1;
+    auto tap_buffer = [&](int slot) -> uint32_t {  // slot = tap index modulo NBUF
+        return slot < 2 ? (uint32_t)(LDS_W + slot * TAP_BYTES) : (uint32_t)ACT_REGION;
+    };
+    auto prefetch = [&](int T, int slot) {
+        const uint8_t* src = p.conv_w + (size_t)T * TAP_BYTES + wave_u * 8192 + lane * 16;
+        const uint32_t dst = lds_base + tap_buffer(slot) + wave_u * 8192;
+        glds16x8(src + 4096, __builtin_amdgcn_readfirstlane(dst + 4096));
+    };
+    auto prefetch_bias = [&](int c) {
+        if (wave_u < 2)
+            glds4(reinterpret_cast<const uint8_t*>(p.conv_b + (size_t)c * CH) + wave_u * 256 + lane * 4,
+                  __builtin_amdgcn_readfirstlane(lds_base + LDS_BIAS + (c & 1) * 512 + wave_u * 256));
+    };
+    auto prefetch_se = [&](int blk, int piece) {
+        if (piece < SE_PIECES)
+            glds16(p.se_img + (size_t)blk * SE_BYTES + piece * 1024 + lane * 16,
+                   __builtin_amdgcn_readfirstlane(lds_base + LDS_SE + piece * 1024));
+    };
+#pragma unroll
+    for (int t = 0; t < AHEAD; ++t) prefetch(t, t);
+    prefetch_bias(0);
+
+    uint32_t aaddr[9][2];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const int px = pt * 32 + r;
+            const int y = (px >> 3) + dy, x = (px & 7) + dx;
+            const bool ok = (y >= 0) && (y < 8) && (x >= 0) && (x < 8);
+            aaddr[tap][pt] = ok ? (uint32_t)(lp * ACT_REGION + (y * 8 + x) * ACT_PITCH + h * 16)
+                                : (uint32_t)(LDS_ZERO + h * 16);
+        }
+    }
+
+    f32x16 acc[NT][2];
+    uint32_t resid[NT][2][8];
+
+    // ---------------- stem
+    {
+        const uint64_t mine = live ? p.mine[pos] : 0ull, theirs = live ? p.theirs[pos] : 0ull;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(p.stem_b + (nt0 + nt) * 32 + gq * 8 + h * 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { acc[nt][0][gq * 4 + q] = b[q]; acc[nt][1][gq * 4 + q] = b[q]; }
+            }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 xb[2];
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                const int px = pt * 32 + r;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = ks * 16 + h * 8 + j;  // k = tap*3 + plane
+                    const int tap = k / 3, pl = k - tap * 3;
+                    const int y = (px >> 3) + tap / 3 - 1, x = (px & 7) + tap % 3 - 1;
+                    const bool ok = (k < 27) && (y >= 0) && (y < 8) && (x >= 0) && (x < 8);
+                    const int sq = (y * 8 + x) & 63;
+                    const uint64_t src = (pl == 0) ? mine : ((pl == 1) ? theirs : ~0ull);
+                    xb[pt][j] = (__bf16)((ok && ((src >> sq) & 1ull)) ? 1.0f : 0.0f);
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const bf16x8 w = *reinterpret_cast<const bf16x8*>(p.stem_w + ((ks * 4 + nt0 + nt) * 64 + lane) * 16);
+                acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, xb[0], acc[nt][0], 0, 0, 0);
+                acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, xb[1], acc[nt][1], 0, 0, 0);
+            }
+        }
+        store_act_n<NT, true, true>(region, acc, resid, r, h, nt0);
+    }
+    wait_weights();
+    __syncthreads();  // the first taps landed, zero row and every channel group's stem output visible
+
+    for (int conv = 0; conv < nconv; ++conv) {
+        {
+            const float* b0 = reinterpret_cast<const float*>(lds + LDS_BIAS + (conv & 1) * 512) + h * 4;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(b0 + (nt0 + nt) * 32 + gq * 8);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { acc[nt][0][gq * 4 + q] = b[q]; acc[nt][1][gq * 4 + q] = b[q]; }
+                }
+        }
+        // Activation fragments run one tap ahead of the MFMAs (they do not depend on the weight
+        // copy); weight fragments are requested right behind the barrier that publishes their
+        // tap.  A deeper software pipeline does not pay here: with 1.5 fragment reads per MFMA
+        // (twice k_tower's) the LDS is as busy as the matrix pipe.
+        bf16x8 xc[8][2];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            xc[ks][0] = lds_read_frag(lds, aaddr[0][0] + ks * 32);
+            xc[ks][1] = lds_read_frag(lds, aaddr[0][1] + ks * 32);
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int T = conv * 9 + tap;
+            // T modulo NBUF: 9 is a multiple of 3, and conv * 9 + tap has the parity of conv + tap
+            const int slot = (NBUF == 3) ? tap % 3 : ((conv + tap) & 1);
+            if (T + AHEAD < total_taps) prefetch(T + AHEAD, (NBUF == 3) ? (tap + AHEAD) % 3 : (slot ^ 1));
+            if (tap == 0 && conv + 1 < nconv) prefetch_bias(conv + 1);
+            if ((conv & 1) && tap < 7 && conv < nconv - 1) prefetch_se(conv >> 1, tap * 4 + wave_u);
+            const uint32_t wb = tap_buffer(slot) + lane * 16 + nt0 * 1024;
+            bf16x8 w[8][NT], xn[8][2];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) w[ks][nt] = lds_read_frag(lds, wb + (ks * 4 + nt) * 1024);
+            if (tap + 1 < 9) {
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    xn[ks][0] = lds_read_frag(lds, aaddr[tap + 1 < 9 ? tap + 1 : 0][0] + ks * 32);
+                    xn[ks][1] = lds_read_frag(lds, aaddr[tap + 1 < 9 ? tap + 1 : 0][1] + ks * 32);
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks][nt], xc[ks][0], acc[nt][0], 0, 0, 0);
+                    acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks][nt], xc[ks][1], acc[nt][1], 0, 0, 0);
+                }
+            // The next tap has landed when at most the copies issued after it are in flight: the 8
+            // of the tap after it (AHEAD = 2); bias / SE pieces in between only make the wait
+            // stricter.  Behind the last tap of a conv everything is awaited: the SE image and the
+            // bias are read next.
+            if (AHEAD == 2 && tap < 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else wait_weights();
+            __syncthreads();  // next tap visible; everyone is done reading this buffer and, after tap 8, the activations
+            if (tap + 1 < 9) {
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) { xc[ks][0] = xn[ks][0]; xc[ks][1] = xn[ks][1]; }
+            }
+        }
+        if (conv == nconv - 1) {
+            // ---- policy conv: ReLU -> LDS -> p_act
+            store_act_n<NT, true, false>(region, acc, resid, r, h, nt0);
+            __syncthreads();
+            if (live) {
+                char* out = reinterpret_cast<char*>(p.p_act) + (size_t)(pos >> 4) * (POLICY_K / 32) * 1024 + (pos & 15) * 64;
+                for (int i = cw; i < 16; i += WPP) {
+                    const int idx = i * 64 + lane;
+                    const uint4 v = *reinterpret_cast<const uint4*>(region + (idx >> 4) * ACT_PITCH + (idx & 15) * 16);
+                    *reinterpret_cast<uint4*>(out + (idx >> 2) * 1024 + (idx & 3) * 16) = v;
+                }
+            }
+        } else if ((conv & 1) == 0) {
+            store_act_n<NT, true, false>(region, acc, resid, r, h, nt0);
+            __syncthreads();
+        } else {
+            const float* se = reinterpret_cast<const float*>(lds + LDS_SE);
+            // squeeze of this wave's channels
+            {
+                float rowsum[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    f32x16 v = acc[nt][0] + acc[nt][1];
+#pragma unroll
+                    for (int step = 0; step < 4; ++step) {
+                        const int half = 8 >> step;
+                        const bool up = (r & half) != 0;
+#pragma unroll
+                        for (int i = 0; i < half; ++i) {
+                            float a = v[i], bq = v[i + half];
+                            asm("" : "+v"(a));
+                            const float send = up ? a : bq;
+                            const float keepv = up ? bq : a;
+                            v[i] = keepv + lane_xor(send, half);
+                        }
+                    }
+                    rowsum[nt] = v[0];
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float tot = rowsum[nt] + __shfl_xor(rowsum[nt], 16);
+                    const int idx = r & 15;
+                    const int ch = (nt0 + nt) * 32 + (idx >> 2) * 8 + h * 4 + (idx & 3);
+                    if (r < 16) scratch[ch] = tot * (1.0f / 64.0f);
+                }
+            }
+            __syncthreads();  // the means of every channel group
+            // fc1 (128 -> 16) + ReLU, by every wave of the position for itself
+            {
+                const int j = lane & 15, q4 = lane >> 4;
+                const float* w1 = se + j * SE_W1_PITCH + q4 * 32;
+                float y = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(w1 + i * 4);
+                    const f32x4 m = *reinterpret_cast<const f32x4*>(scratch + q4 * 32 + i * 4);
+                    y += w[0] * m[0] + w[1] * m[1] + w[2] * m[2] + w[3] * m[3];
+                }
+                y += __shfl_xor(y, 16);
+                y += __shfl_xor(y, 32);
+                y = fmaxf(y + se[SE_OFF_B1 + j], 0.f);
+                if (lane < 16) scratch[128 + cw * 16 + lane] = y;
+            }
+            wave_lds_sync();
+            // fc2 for this wave's channels: lanes 0-31 the gates, lanes 32-63 the shifts
+            {
+                f32x4 hid[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hid[i] = *reinterpret_cast<const f32x4*>(scratch + 128 + cw * 16 + i * 4);
+#pragma unroll
+                for (int m = 0; m < NT; ++m) {
+                    const int col = h * CH + (nt0 + m) * 32 + r;
+                    const float* w2c = se + SE_OFF_W2 + col;
+                    float wv[17];
+#pragma unroll
+                    for (int jj = 0; jj < 17; ++jj) wv[jj] = w2c[jj * 256];
+                    float g = wv[16];
+#pragma unroll
+                    for (int jj = 0; jj < 16; ++jj) g += wv[jj] * hid[jj >> 2][jj & 3];
+                    const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-g));
+                    scratch[192 + col] = h ? g : sg;
+                }
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int ch0 = (nt0 + nt) * 32 + gq * 8 + h * 4;
+                    const f32x4 gt = *reinterpret_cast<const f32x4*>(scratch + 192 + ch0);
+                    const f32x4 sh = *reinterpret_cast<const f32x4*>(scratch + 192 + CH + ch0);
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt) {
+                        const uint32_t rlo = resid[nt][pt][gq * 2 + 0], rhi = resid[nt][pt][gq * 2 + 1];
+                        acc[nt][pt][gq * 4 + 0] = acc[nt][pt][gq * 4 + 0] * gt[0] + sh[0] + bf16_lo(rlo);
+                        acc[nt][pt][gq * 4 + 1] = acc[nt][pt][gq * 4 + 1] * gt[1] + sh[1] + bf16_hi(rlo);
+                        acc[nt][pt][gq * 4 + 2] = acc[nt][pt][gq * 4 + 2] * gt[2] + sh[2] + bf16_lo(rhi);
+                        acc[nt][pt][gq * 4 + 3] = acc[nt][pt][gq * 4 + 3] * gt[3] + sh[3] + bf16_hi(rhi);
+                    }
+                }
+            }
+            store_act_n<NT, true, true>(region, acc, resid, r, h, nt0);
+            __syncthreads();
+            if (conv == nconv - 2 && cw == 0) {
+                // ---- value head conv 1x1 (128 -> 32) on the tower output, by the first wave of the position
+                f32x16 va[2];
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) va[pt][v] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const bf16x8 w = *reinterpret_cast<const bf16x8*>(p.value_w + (ks * 64 + lane) * 16);
+                    const bf16x8 x0 = lds_read_frag(lds, aaddr[4][0] + ks * 32);
+                    const bf16x8 x1 = lds_read_frag(lds, aaddr[4][1] + ks * 32);
+                    va[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x0, va[0], 0, 0, 0);
+                    va[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x1, va[1], 0, 0, 0);
+                }
+                if (live) {
+                    char* out = reinterpret_cast<char*>(p.v_act) + (size_t)(pos >> 4) * (VALUE_K / 32) * 1024 + (pos & 15) * 64;
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int ch0 = gq * 8 + h * 4;
+                        const f32x4 b = *reinterpret_cast<const f32x4*>(p.value_b + ch0);
+#pragma unroll
+                        for (int pt = 0; pt < 2; ++pt) {
+                            const float v0 = fmaxf(va[pt][gq * 4 + 0] + b[0], 0.f);
+                            const float v1 = fmaxf(va[pt][gq * 4 + 1] + b[1], 0.f);
+                            const float v2 = fmaxf(va[pt][gq * 4 + 2] + b[2], 0.f);
+                            const float v3 = fmaxf(va[pt][gq * 4 + 3] + b[3], 0.f);
+                            *reinterpret_cast<uint2*>(out + (pt * 32 + r) * 1024 + ch0 * 2) =
+                                make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Head GEMMs: out_part[chunk][pos][N] = act[pos][chunk K-range] . W[n][same K-range]
 // v_mfma_f32_16x16x32_bf16, 16 positions per workgroup, wave w owns NTW n-tiles.
 struct HeadParams {
@@ -973,7 +1311,14 @@ int az::net_forward_partial(az_net* n, int32_t B, const uint64_t* mine_dev, cons
     tp.stamps = n->stamps;
     const bool stamp = n->timing && (n->launches++ % TIMING_STRIDE == 0) && n->ev_used < TIMING_POOL;
     if (stamp) AZ_HIP(hipEventRecord(n->ev0[n->ev_used], s));
-    hipLaunchKernelGGL(k_tower, dim3((B + 3) / 4), dim3(256), 0, s, tp);
+    // form of the tower: whole positions per wave from 513 positions up, channel-split waves
+    // below (AZ_TOWER_FORM = 1, 2 or 4 forces one; the cycle stamps exist in the first only)
+    static const int forced = getenv("AZ_TOWER_FORM") ? atoi(getenv("AZ_TOWER_FORM")) : 0;
+    int form = forced ? forced : (B <= 256 ? 1 : (B <= 512 ? 2 : 4));
+    if (n->stamps || dbg) form = 4;
+    if (form == 1) hipLaunchKernelGGL(k_tower_split<1>, dim3(B), dim3(256), 0, s, tp);
+    else if (form == 2) hipLaunchKernelGGL(k_tower_split<2>, dim3((B + 1) / 2), dim3(256), 0, s, tp);
+    else hipLaunchKernelGGL(k_tower, dim3((B + 3) / 4), dim3(256), 0, s, tp);
     if (stamp) AZ_HIP(hipEventRecord(n->ev1[n->ev_used++], s));
     HeadParams hp{n->p_act, n->v_act, n->wp, n->wv, n->part_p, n->part_v, B};
     hipLaunchKernelGGL(k_head_gemm, dim3((B + 16 * HEAD_MT - 1) / (16 * HEAD_MT), POLICY_CHUNKS + VALUE_CHUNKS), dim3(256), 0, s, hp);

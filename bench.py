@@ -219,7 +219,8 @@ def main():
                        "parallelism": f"games sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_BF16_DENSE / 1e12,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_DENSE, "traffic": traffic,
-                         "kernel": "k_tower", "launch_ms": tower_ms, "launch_samples": tower_samples,
+                         "kernel": "k_tower" if args.games > 512 else ("k_tower_split<2>" if args.games > 256 else "k_tower_split<1>"),
+                         "launch_ms": tower_ms, "launch_samples": tower_samples,
                          "flop_per_launch": flop_launch,
                          "mean_search_depth": eng.mean_depth()},
         }
