@@ -104,6 +104,12 @@ def test_batch_4096_full_network():
     p2, v2, _, _ = inf.forward_planes(x[sub].contiguous().cuda())
     assert np.array_equal(p2.cpu().numpy().view(np.uint32), probs[sub].view(np.uint32))
     assert np.array_equal(v2.cpu().numpy().view(np.uint32), value[sub].view(np.uint32))
+    # the small-batch forms of the tower (channel-split waves: up to 256 and up to 512 positions)
+    # compute the same network: equal to the large-batch form up to summation order
+    for count in (200, 400):
+        p3, v3, _, _ = inf.forward_planes(x[sub[:count]].contiguous().cuda())
+        assert np.abs(p3.cpu().numpy() - probs[sub[:count]]).max() < 1e-3
+        assert np.abs(v3.cpu().numpy() - value[sub[:count]]).max() < 1e-2
 
 
 def test_matches_reference_logits_fixture(golden_dir):
