@@ -603,10 +603,13 @@ __device__ __forceinline__ void store_act_n(char* region, const f32x16 (&acc)[NT
     }
 }
 
-template <int NT>
-__global__ __launch_bounds__(256, 1) void k_tower_split(TowerParams p) {
-    constexpr int WPP = 4 / NT;  // waves per position
-    static_assert(NT == 1 || NT == 2, "a whole position per wave is k_tower");
+template <int NT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 1) void k_tower_split(TowerParams p) {
+    constexpr int WPP = 4 / NT;        // waves per position
+    constexpr int PPW = WAVES / WPP;   // positions per workgroup
+    // WAVES = 8 (NT = 2, four positions): two waves per SIMD, one's LDS and barrier waits run
+    // under the other's MFMAs
+    static_assert((NT == 1 || NT == 2) && (WAVES == 4 || (WAVES == 8 && NT == 2)), "a whole position per wave is k_tower");
     __shared__ __attribute__((aligned(1024))) char lds[LDS_TOTAL];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -615,15 +618,18 @@ __global__ __launch_bounds__(256, 1) void k_tower_split(TowerParams p) {
     const int lp = wave_u / WPP;            // position of this wave inside the workgroup
     const int cw = wave_u % WPP;            // its channel group
     const int nt0 = cw * NT;                // first channel tile of the group
-    const int pos = blockIdx.x * NT + lp;
+    const int pos = blockIdx.x * PPW + lp;
     const bool live = pos < p.B;
     char* region = lds + lp * ACT_REGION;
-    // floats: [0,128) channel means, [128 + 16 cw, +16) hidden layer (per wave), [192,320) gates, [320,448) shifts
-    float* scratch = reinterpret_cast<float*>(lds + 3 * ACT_REGION + lp * 2048);
+    // floats: [0,128) channel means, [128 + 16 cw, +16) hidden layer (per wave), [192,320) gates, [320,448) shifts.
+    // With spare activation regions (WAVES = 4) it lives there; otherwise in the position's own
+    // region, which nobody reads between a block's last tap and the block's output store.
+    float* scratch = (WAVES == 4) ? reinterpret_cast<float*>(lds + 3 * ACT_REGION + lp * 2048)
+                                  : reinterpret_cast<float*>(region);
     const int nconv = 2 * p.blocks + 1;
     const int total_taps = nconv * 9;
 
-    for (int i = tid; i < 512 / 4; i += 256) reinterpret_cast<uint32_t*>(lds + LDS_ZERO)[i] = 0;
+    if (tid < 512 / 4) reinterpret_cast<uint32_t*>(lds + LDS_ZERO)[tid] = 0;
 
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_void*)lds;
     // Weight taps: NT = 1 runs a tap in well under a microsecond, less than an L2 -> LDS copy
@@ -634,9 +640,16 @@ __global__ __launch_bounds__(256, 1) void k_tower_split(TowerParams p) {
         return slot < 2 ? (uint32_t)(LDS_W + slot * TAP_BYTES) : (uint32_t)ACT_REGION;
     };
     auto prefetch = [&](int T, int slot) {
-        const uint8_t* src = p.conv_w + (size_t)T * TAP_BYTES + wave_u * 8192 + lane * 16;
-        const uint32_t dst = lds_base + tap_buffer(slot) + wave_u * 8192;
-        glds16x8(src + 4096, __builtin_amdgcn_readfirstlane(dst + 4096));
+        if (WAVES == 4) {
+            const uint8_t* src = p.conv_w + (size_t)T * TAP_BYTES + wave_u * 8192 + lane * 16;
+            const uint32_t dst = lds_base + tap_buffer(slot) + wave_u * 8192;
+            glds16x8(src + 4096, __builtin_amdgcn_readfirstlane(dst + 4096));
+        } else {
+            const uint8_t* src = p.conv_w + (size_t)T * TAP_BYTES + wave_u * 4096 + lane * 16;
+            const uint32_t dst = lds_base + tap_buffer(slot) + wave_u * 4096;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) glds16(src + i * 1024, __builtin_amdgcn_readfirstlane(dst + i * 1024));
+        }
     };
     auto prefetch_bias = [&](int c) {
         if (wave_u < 2)
@@ -726,10 +739,12 @@ __global__ __launch_bounds__(256, 1) void k_tower_split(TowerParams p) {
         // tap.  A deeper software pipeline does not pay here: with 1.5 fragment reads per MFMA
         // (twice k_tower's) the LDS is as busy as the matrix pipe.
         bf16x8 xc[8][2];
+        if constexpr (WAVES == 4) {
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            xc[ks][0] = lds_read_frag(lds, aaddr[0][0] + ks * 32);
-            xc[ks][1] = lds_read_frag(lds, aaddr[0][1] + ks * 32);
+            for (int ks = 0; ks < 8; ++ks) {
+                xc[ks][0] = lds_read_frag(lds, aaddr[0][0] + ks * 32);
+                xc[ks][1] = lds_read_frag(lds, aaddr[0][1] + ks * 32);
+            }
         }
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -738,8 +753,35 @@ __global__ __launch_bounds__(256, 1) void k_tower_split(TowerParams p) {
             const int slot = (NBUF == 3) ? tap % 3 : ((conv + tap) & 1);
             if (T + AHEAD < total_taps) prefetch(T + AHEAD, (NBUF == 3) ? (tap + AHEAD) % 3 : (slot ^ 1));
             if (tap == 0 && conv + 1 < nconv) prefetch_bias(conv + 1);
-            if ((conv & 1) && tap < 7 && conv < nconv - 1) prefetch_se(conv >> 1, tap * 4 + wave_u);
+            if ((conv & 1) && tap < 7 && conv < nconv - 1) prefetch_se(conv >> 1, tap * WAVES + wave_u);
             const uint32_t wb = tap_buffer(slot) + lane * 16 + nt0 * 1024;
+            if constexpr (WAVES == 8) {
+                // 256 registers per wave: fragments one k-step ahead only; the other wave of the
+                // SIMD covers what this leaves exposed
+                bf16x8 fw[2][NT], fx[2][2];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) fw[0][nt] = lds_read_frag(lds, wb + nt * 1024);
+                fx[0][0] = lds_read_frag(lds, aaddr[tap][0]);
+                fx[0][1] = lds_read_frag(lds, aaddr[tap][1]);
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const int c = ks & 1, n = c ^ 1;
+                    if (ks + 1 < 8) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) fw[n][nt] = lds_read_frag(lds, wb + ((ks + 1) * 4 + nt) * 1024);
+                        fx[n][0] = lds_read_frag(lds, aaddr[tap][0] + (ks + 1) * 32);
+                        fx[n][1] = lds_read_frag(lds, aaddr[tap][1] + (ks + 1) * 32);
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[c][nt], fx[c][0], acc[nt][0], 0, 0, 0);
+                        acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[c][nt], fx[c][1], acc[nt][1], 0, 0, 0);
+                    }
+                }
+                wait_weights();
+                __syncthreads();
+                continue;
+            }
             bf16x8 w[8][NT], xn[8][2];
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks)
@@ -872,6 +914,7 @@ __global__ __launch_bounds__(256, 1) void k_tower_split(TowerParams p) {
                     }
                 }
             }
+            if (WAVES == 8) __syncthreads();  // every wave has read its gates: the scratch may be overwritten
             store_act_n<NT, true, true>(region, acc, resid, r, h, nt0);
             __syncthreads();
             if (conv == nconv - 2 && cw == 0) {
@@ -1316,8 +1359,9 @@ int az::net_forward_partial(az_net* n, int32_t B, const uint64_t* mine_dev, cons
     static const int forced = getenv("AZ_TOWER_FORM") ? atoi(getenv("AZ_TOWER_FORM")) : 0;
     int form = forced ? forced : (B <= 256 ? 1 : (B <= 512 ? 2 : 4));
     if (n->stamps || dbg) form = 4;
-    if (form == 1) hipLaunchKernelGGL(k_tower_split<1>, dim3(B), dim3(256), 0, s, tp);
-    else if (form == 2) hipLaunchKernelGGL(k_tower_split<2>, dim3((B + 1) / 2), dim3(256), 0, s, tp);
+    if (form == 1) hipLaunchKernelGGL((k_tower_split<1, 4>), dim3(B), dim3(256), 0, s, tp);
+    else if (form == 2) hipLaunchKernelGGL((k_tower_split<2, 4>), dim3((B + 1) / 2), dim3(256), 0, s, tp);
+    else if (form == 8) hipLaunchKernelGGL((k_tower_split<2, 8>), dim3((B + 3) / 4), dim3(512), 0, s, tp);
     else hipLaunchKernelGGL(k_tower, dim3((B + 3) / 4), dim3(256), 0, s, tp);
     if (stamp) AZ_HIP(hipEventRecord(n->ev1[n->ev_used++], s));
     HeadParams hp{n->p_act, n->v_act, n->wp, n->wv, n->part_p, n->part_v, B};
