@@ -85,15 +85,24 @@ def losses(model, states, target_pis, target_wls):
     return loss_pi + loss_wl, loss_pi, loss_wl
 
 
-def train_step(model, optimizer, states, target_pis, target_wls, group=None):
+def train_step(model, optimizer, states, target_pis, target_wls, group=None, autocast_dtype=None):
     """One optimisation step on this rank's slice of the batch; gradients are
     averaged over the ranks of `group` when torch.distributed is initialised.  A
     rank whose slice is empty (ragged last batch) contributes zero gradients and
-    still joins the all-reduce."""
+    still joins the all-reduce.  autocast_dtype (e.g. torch.bfloat16) runs the
+    forward under torch.autocast; None is the reference's float32 step."""
     model.train()
     optimizer.zero_grad()
     if states.shape[0] > 0:
-        loss, loss_pi, loss_wl = losses(model, states, target_pis, target_wls)
+        if autocast_dtype is None:
+            loss, loss_pi, loss_wl = losses(model, states, target_pis, target_wls)
+        else:
+            with torch.autocast(device_type=states.device.type, dtype=autocast_dtype):
+                pred_pis, pred_wls = model(states)
+            log_probs = F.log_softmax(pred_pis.float(), dim=1)
+            loss_pi = -torch.sum(target_pis * log_probs) / target_pis.size(0)
+            loss_wl = F.cross_entropy(pred_wls.float(), target_wls)
+            loss = loss_pi + loss_wl
         loss.backward()
         out = (float(loss.detach()), float(loss_pi.detach()), float(loss_wl.detach()))
     else:

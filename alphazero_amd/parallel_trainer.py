@@ -145,12 +145,15 @@ def gather_batch(states, policies, wls, idx, mirror_perm):
 class ParallelTrainer:
     """Same constructor, attributes and methods as the reference's trainer
     (src/parallel_trainer.py:101-476).  `seed` (extra) seeds the device RNG of
-    the fused self-play path; `verbose` (extra) enables the progress prints."""
+    the fused self-play path; `verbose` (extra) enables the progress prints;
+    `autocast_dtype` (extra, default None = float32 like the reference) runs the
+    training forward under torch.autocast."""
 
     def __init__(self, model: AlphaZeroNet, device: str = "cpu",
                  num_parallel_games: int = Config.PARALLEL_GAMES,
                  num_simulations: int = Config.MCTS_SIMULATIONS,
-                 checkpoint_dir: str = Config.CHECKPOINT_DIR, seed: int = 0, verbose: bool = True):
+                 checkpoint_dir: str = Config.CHECKPOINT_DIR, seed: int = 0, verbose: bool = True,
+                 autocast_dtype=None):
         self.model = model
         self.device = device
         self.num_parallel_games = num_parallel_games
@@ -164,6 +167,7 @@ class ParallelTrainer:
         self.checkpoint_dir = checkpoint_dir
         self.seed = seed
         self.verbose = verbose
+        self.autocast_dtype = autocast_dtype   # None: the reference's float32 step; torch.bfloat16: autocast forward
         self._selfplay = None          # fused device self-play, built on first use
         self._weights_changed = False  # the HIP inference copy is stale
         os.makedirs(self.checkpoint_dir, exist_ok=True)
@@ -281,7 +285,7 @@ class ParallelTrainer:
                 if world > 1:
                     idx = idx[rank::world]
                 s, p, w = gather_batch(states, policies, wls, idx.to(dev), perm)
-                tot += azdist.train_step(self.model, self.optimizer, s, p, w)
+                tot += azdist.train_step(self.model, self.optimizer, s, p, w, autocast_dtype=self.autocast_dtype)
                 count += 1
             stats = dict(zip(("loss", "pi", "wl"), (tot / max(count, 1)).tolist()))
         self.scheduler.step()
