@@ -2,11 +2,12 @@
 // on gfx950.  HBM-bound integer work: 17 B in, 25 B out per position for the
 // packed outputs; 192 B more for the byte mask and 768 B more for float planes.
 //
-// Work split: the packed outputs are one position per lane (three shifts and
-// masks on two u64 words).  The byte mask and the float planes are written by
-// a whole wavefront per position group so that every store instruction covers
-// contiguous bytes: a wave walks its 64 positions and writes each one's 192
-// mask bytes as 48 lanes x 4 B and its 768 plane bytes as 48 lanes x 16 B.
+// Work split: one position per lane for the arithmetic (three shifts and masks
+// on two u64 words).  Every output is then written so that one store
+// instruction of the wave covers contiguous bytes: the wave's 64 x 3 source
+// masks are exchanged across lanes and leave as three 512-byte stores, the
+// byte masks of its 64 positions (12 KB) as twelve 1 KB stores of 16 B per
+// lane, the float planes (48 KB) as 48 lanes x 16 B per position.
 #include "az_common.h"
 
 namespace az {
@@ -32,11 +33,6 @@ __global__ __launch_bounds__(256) void movegen_kernel(
             mine = (t > 0) ? w : bitrev64(b);
             theirs = (t > 0) ? b : bitrev64(w);
             l = legal_sources(mine, theirs);
-            if (legal3) {
-                legal3[3 * i + 0] = l.fwd;
-                legal3[3 * i + 1] = l.dl;
-                legal3[3 * i + 2] = l.dr;
-            }
             if (status) {
                 int s = 0;
                 if (w & ROW_7) s = 1;
@@ -47,27 +43,56 @@ __global__ __launch_bounds__(256) void movegen_kernel(
                 status[i] = (int8_t)s;
             }
         }
-        if (MASK || PLANES) {
-            const int cnt = (n - base < 64) ? (int)(n - base) : 64;
+        const int cnt = (n - base < 64) ? (int)(n - base) : 64;
+        if (legal3) {
+            // word e = 64 k + lane of the group's 192 output words belongs to position e / 3,
+            // direction e % 3: fetch it from that lane, store 512 contiguous bytes per k
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int e = 64 * k + lane;
+                const int src = e / 3, d = e - 3 * src;
+                const uint64_t f = __shfl(l.fwd, src), dl = __shfl(l.dl, src), dr = __shfl(l.dr, src);
+                if (src < cnt) legal3[3 * base + e] = (d == 0) ? f : ((d == 1) ? dl : dr);
+            }
+        }
+        if (MASK) {
+            // 16-byte piece c = 64 k + lane of the group's 64 x 12 pieces: position c / 12, piece
+            // m = c % 12 = actions 16 m .. 16 m + 15.  Action a = 3 sq + dir, and 16 = 1 (mod 3):
+            // with r = m % 3 and sq0 = (16 m - r) / 3, action 16 m + q has dir (r + q) % 3 and
+            // square sq0 + (r + q) / 3.  Rotating the three source masks by r (and pre-shifting
+            // the rotated ones that carry into the next square) leaves constant shifts per q.
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                const int c = 64 * k + lane;
+                const int src = c / 12, m = c - 12 * src;
+                const int r = m % 3, sq0 = (16 * m - r) / 3;
+                const uint64_t f = __shfl(l.fwd, src), dl = __shfl(l.dl, src), dr = __shfl(l.dr, src);
+                const uint32_t s0 = (uint32_t)(f >> sq0), s1 = (uint32_t)(dl >> sq0), s2 = (uint32_t)(dr >> sq0);
+                // u[j]: mask of direction (r + j) % 3, shifted so that bit q / 3 is action q's (q % 3 == j)
+                const uint32_t u0 = (r == 0) ? s0 : ((r == 1) ? s1 : s2);
+                const uint32_t u1 = (r == 0) ? s1 : ((r == 1) ? s2 : (s0 >> 1));
+                const uint32_t u2 = (r == 0) ? s2 : ((r == 1) ? (s0 >> 1) : (s1 >> 1));
+                uint32_t word[4];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    uint32_t wv = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int qq = 4 * q4 + q;
+                        const uint32_t u = (qq % 3 == 0) ? u0 : ((qq % 3 == 1) ? u1 : u2);
+                        wv |= ((u >> (qq / 3)) & 1u) << (8 * q);
+                    }
+                    word[q4] = wv;
+                }
+                if (src < cnt)
+                    *reinterpret_cast<uint4*>(mask192 + 192 * base + 16 * (int64_t)c) = make_uint4(word[0], word[1], word[2], word[3]);
+            }
+        }
+        if (PLANES) {
             for (int j = 0; j < cnt; ++j) {
                 // position j of this group, broadcast from lane j (all lanes take part)
                 const uint64_t m = __shfl(mine, j), th = __shfl(theirs, j);
-                if (MASK) {
-                    const uint64_t f = __shfl(l.fwd, j), dl = __shfl(l.dl, j), dr = __shfl(l.dr, j);
-                    if (lane < 48) {
-                        // bytes 4*lane .. 4*lane+3 of the 192-byte row: action a = sq*3+dir
-                        uint32_t word = 0;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int a = 4 * lane + q;
-                            const int sq = a / 3, d = a - 3 * sq;
-                            const uint64_t src = (d == 0) ? f : ((d == 1) ? dl : dr);
-                            word |= (uint32_t)((src >> sq) & 1ull) << (8 * q);
-                        }
-                        reinterpret_cast<uint32_t*>(mask192 + 192 * (base + j))[lane] = word;
-                    }
-                }
-                if (PLANES && lane < 48) {
+                if (lane < 48) {
                     // floats 4*lane .. 4*lane+3 of the 192-float image [3][8][8]
                     const int p = lane >> 4;              // plane
                     const int s0 = (4 * lane) & 63;       // first square
@@ -93,8 +118,9 @@ extern "C" int az_movegen_encode(int64_t n, const uint64_t* white_dev, const uin
     AZ_CHECK_ARG(n >= 0, "az_movegen_encode: n = %lld < 0", (long long)n);
     if (n == 0) return AZ_OK;
     AZ_CHECK_ARG(white_dev && black_dev && turn_dev, "az_movegen_encode: null input pointer");
-    AZ_CHECK_ARG(((uintptr_t)planes_dev & 15) == 0 && ((uintptr_t)mask192_dev & 3) == 0,
-                 "az_movegen_encode: planes must be 16-byte and mask 4-byte aligned");
+    AZ_CHECK_ARG(((uintptr_t)planes_dev & 15) == 0 && ((uintptr_t)mask192_dev & 15) == 0 &&
+                     ((uintptr_t)legal3_dev & 7) == 0,
+                 "az_movegen_encode: planes and mask must be 16-byte aligned, legal3 8-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int64_t groups = (n + 63) / 64;  // one wave per 64 positions
     int64_t blocks = (groups + 3) / 4;
