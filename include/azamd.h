@@ -46,7 +46,8 @@ int az_version(void);
  *   status_dev  [n] i8  0 live; +1 / -1 a side has won on the board (a piece
  *                       on its goal row, or the other side extinct); 2 the
  *                       side to move has no legal move
- * Any output pointer may be NULL.  n may be 0.
+ * Any output pointer may be NULL.  n may be 0.  mask192_dev and planes_dev must
+ * be 16-byte aligned, legal3_dev 8-byte aligned (AZ_ERR_ARG otherwise).
  */
 int az_movegen_encode(int64_t n, const uint64_t* white_dev, const uint64_t* black_dev,
                       const int8_t* turn_dev, uint64_t* legal3_dev, uint8_t* mask192_dev,
