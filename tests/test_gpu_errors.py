@@ -1,0 +1,79 @@
+"""GPU: error behaviour of the C ABI — every misuse is reported as a negative status
+with a message (AzError in the Python wrappers), never as a fault or a silent no-op."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def test_call_sequence_is_checked():
+    from alphazero_amd._lib import AzError
+    from alphazero_amd.engine import Engine
+    e = Engine(4, pool_nodes_per_game=256)
+    e.reset_all()
+    e.set_active(np.ones(4, np.uint8))
+    with pytest.raises(AzError, match="without az_engine_select"):
+        e.expand_backup(e.probs, e.values)
+    with pytest.raises(AzError, match="without az_engine_roots_prepare"):
+        e.roots_expand(e.probs)
+    with pytest.raises(AzError, match="no network attached"):
+        e.search(4)
+
+
+def test_argument_ranges_are_checked():
+    from alphazero_amd import _lib
+    from alphazero_amd._lib import AzError
+    from alphazero_amd.engine import Engine
+    from alphazero_amd.model import AlphaZeroNet, HipInference
+    e = Engine(4, pool_nodes_per_game=256)
+    with pytest.raises(AzError, match="out of range"):
+        e.set_positions([4], [0xFFFF], [0xFFFF << 48], [1])
+    with pytest.raises(AzError, match="out of range"):
+        e.set_roots([9], [0])
+    with pytest.raises(AzError, match="out of range"):
+        e.node_children(7)
+    inf = HipInference(AlphaZeroNet(num_blocks=1, num_filters=128), max_batch=16)
+    with pytest.raises(AzError, match="exceeds max_batch"):
+        inf.forward_planes(torch.ones((17, 3, 8, 8), device="cuda"))
+    L = _lib.lib()
+    with pytest.raises(AzError, match="n_games"):
+        Engine(0)
+    with pytest.raises(AzError, match="pool_nodes_per_game"):
+        Engine(4, pool_nodes_per_game=8)
+    # movegen: a mask pointer that is not 16-byte aligned
+    w = torch.tensor([0xFFFF], dtype=torch.int64, device="cuda")
+    b = torch.tensor([-(1 << 48)], dtype=torch.int64, device="cuda")
+    t = torch.ones(1, dtype=torch.int8, device="cuda")
+    mask = torch.zeros(256, dtype=torch.uint8, device="cuda")
+    rc = L.az_movegen_encode(1, C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(t.data_ptr()), None,
+                             C.c_void_p(mask.data_ptr() + 4), None, None, _stream())
+    assert rc == -1 and b"aligned" in L.az_last_error()
+    rc = L.az_movegen_encode(-1, C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(t.data_ptr()), None,
+                             None, None, None, _stream())
+    assert rc == -1
+    assert L.az_movegen_encode(0, None, None, None, None, None, None, None, _stream()) == 0   # empty input is fine
+
+
+def test_capacity_errors_are_reported_not_silent():
+    from alphazero_amd._lib import AzError
+    from alphazero_amd.engine import Engine
+    from alphazero_amd.model import AlphaZeroNet, HipInference
+    torch.manual_seed(1)
+    inf = HipInference(AlphaZeroNet(num_blocks=1, num_filters=128).eval(), max_batch=16)
+    e = Engine(8, pool_nodes_per_game=128)            # far too small for 64 simulations
+    e.attach_net(inf)
+    e.reset_all()
+    e.set_active(np.ones(8, np.uint8))
+    with pytest.raises(AzError, match="node pool exhausted"):
+        e.search(64)
+        e.pool_usage()
+    # the flag is sticky: later calls on the engine keep reporting it
+    with pytest.raises(AzError, match="node pool exhausted"):
+        e.pool_usage()
