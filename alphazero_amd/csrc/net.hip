@@ -17,6 +17,9 @@
 //                 3x3 conv = 9 taps x 8 k-steps of v_mfma_f32_32x32x16_bf16 with
 //                 D[channel][pixel] = W[channel][k] * X[k][pixel]; a tap is just a
 //                 per-lane LDS address (out-of-board pixels read a zero row).
+//                 Below 513 positions k_tower_split runs instead: the channels of a
+//                 position are split over 4 or 2 waves so that a small batch still
+//                 spreads over the chip (see its comment).
 //   k_head_gemm   policy FC (8192->192) and value FC1 (2048->128) as split-K MFMA
 //                 GEMMs over the bf16 head activations.
 //   k_head_finish bias, ReLU, value FC2, both softmaxes, value = P(win) - P(loss).
