@@ -81,9 +81,9 @@ class AlphaZeroNet(nn.Module):
         for block in self.residual_tower:
             out = block(out)
         policy = F.relu(self.policy_bn(self.policy_conv(out)))
-        policy_logits = self.policy_fc(policy.view(policy.size(0), -1))
+        policy_logits = self.policy_fc(policy.reshape(policy.size(0), -1))
         value = F.relu(self.value_bn(self.value_conv(out)))
-        value = F.relu(self.value_fc1(value.view(value.size(0), -1)))
+        value = F.relu(self.value_fc1(value.reshape(value.size(0), -1)))
         return policy_logits, self.value_fc2(value)
 
     def get_value(self, wl_logits):
