@@ -7,7 +7,7 @@
 // instruction of the wave covers contiguous bytes: the wave's 64 x 3 source
 // masks are exchanged across lanes and leave as three 512-byte stores, the
 // byte masks of its 64 positions (12 KB) as twelve 1 KB stores of 16 B per
-// lane, the float planes (48 KB) as 48 lanes x 16 B per position.
+// lane, the float planes (48 KB) as forty-eight 1 KB stores.
 #include "az_common.h"
 
 namespace az {
@@ -89,21 +89,22 @@ __global__ __launch_bounds__(256) void movegen_kernel(
             }
         }
         if (PLANES) {
-            for (int j = 0; j < cnt; ++j) {
-                // position j of this group, broadcast from lane j (all lanes take part)
-                const uint64_t m = __shfl(mine, j), th = __shfl(theirs, j);
-                if (lane < 48) {
-                    // floats 4*lane .. 4*lane+3 of the 192-float image [3][8][8]
-                    const int p = lane >> 4;              // plane
-                    const int s0 = (4 * lane) & 63;       // first square
-                    const uint64_t src = (p == 0) ? m : ((p == 1) ? th : ~0ull);
-                    float4 v;
-                    v.x = (float)((src >> (s0 + 0)) & 1ull);
-                    v.y = (float)((src >> (s0 + 1)) & 1ull);
-                    v.z = (float)((src >> (s0 + 2)) & 1ull);
-                    v.w = (float)((src >> (s0 + 3)) & 1ull);
-                    reinterpret_cast<float4*>(planes + 192 * (base + j))[lane] = v;
-                }
+            // 16-byte piece c = 64 k + lane of the group's 64 x 48 pieces: position c / 48, piece
+            // m = c % 48 = floats 4 m .. 4 m + 3 of the image [3][8][8] (plane m / 16, squares
+            // 4 (m % 16) ..)
+#pragma unroll 4
+            for (int k = 0; k < 48; ++k) {
+                const int c = 64 * k + lane;
+                const int src = c / 48, m = c - 48 * src;
+                const uint64_t mi = __shfl(mine, src), th = __shfl(theirs, src);
+                const int pl = m >> 4, s0 = (4 * m) & 63;
+                const uint32_t bits = (uint32_t)(((pl == 0) ? mi : ((pl == 1) ? th : ~0ull)) >> s0);
+                float4 v;
+                v.x = (float)(bits & 1u);
+                v.y = (float)((bits >> 1) & 1u);
+                v.z = (float)((bits >> 2) & 1u);
+                v.w = (float)((bits >> 3) & 1u);
+                if (src < cnt) *reinterpret_cast<float4*>(planes + 192 * base + 4 * (int64_t)c) = v;
             }
         }
     }
