@@ -94,3 +94,44 @@ def test_continuous_selfplay_restarts_and_drains(small_model):
     assert len(s) == st["samples_pending"] > 0
     assert sp.engine.stats()["samples_pending"] == 0
     assert st["simulations"] == 150 * 8 * 8
+
+
+def test_full_size_plies_keep_the_search_invariants():
+    """The benchmark configuration itself (1024 games x 800 simulations, 20 x 128 network, root
+    noise): size-independent properties of three plies with tree reuse, checked for every game."""
+    from alphazero_amd.model import AlphaZeroNet
+    from alphazero_amd.selfplay import SelfPlay
+    nG, S = 1024, 800
+    torch.manual_seed(0)
+    sp = SelfPlay(AlphaZeroNet(num_blocks=20, num_filters=128).eval(), n_games=nG, num_simulations=S, seed=77)
+    e = sp.engine
+    pos = [orc.start_position() for _ in range(nG)]
+    carried = np.zeros(nG, np.int64)              # visits the kept subtree brought into this ply
+    slots = np.arange(nG)
+    for ply in range(3):
+        e.search(S, add_noise=True)
+        roots = e.roots_children(slots)
+        for g, q in enumerate(roots):
+            legal = orc.legal_actions(pos[g])
+            assert np.array_equal(q["actions"], legal)                   # children = legal moves, insertion order
+            # a fresh root's value is not backed up; a reused root keeps the visits it had as a child
+            assert q["root_N"] == carried[g] + S
+            # a reused child was visited once as a leaf before it had children of its own
+            assert int(q["N"].sum()) == q["root_N"] - (1 if carried[g] > 0 else 0)
+            assert np.all(q["p_is64"] == 1) and abs(q["P"].sum() - 1.0) < 1e-6   # noise keeps the priors normalised
+        e.play_move(0, add_noise=False, restart_finished=False)           # record, choose, step, re-root
+        acts = e.chosen_actions()
+        w1, b1, t1, win1 = e.get_positions()
+        for g, q in enumerate(roots):
+            a = int(acts[g])
+            i = int(np.flatnonzero(q["actions"] == a)[0])
+            assert q["N"][i] > 0                                          # temperature 1: only visited moves
+            carried[g] = int(q["N"][i])
+            pos[g] = orc.step_action(pos[g], a)
+            assert (pos[g].white, pos[g].black, pos[g].turn) == (int(w1[g]), int(b1[g]), int(t1[g]))
+            assert pos[g].winner == 0 and int(win1[g]) == 0               # nobody wins in three plies
+    assert e.pool_usage().max() < (1 << 18)
+    st = e.stats()
+    assert st["moves"] == 3 * nG and st["simulations"] == 3 * nG * S
+    s, p, wl = e.drain_samples()
+    assert len(s) == 0                                                    # no game has finished
