@@ -805,10 +805,10 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_tower_split(TowerParams p) {
                     acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks][nt], xc[ks][1], acc[nt][1], 0, 0, 0);
                 }
             // The next tap has landed when at most the copies issued after it are in flight: the 8
-            // of the tap after it (AHEAD = 2); bias / SE pieces in between only make the wait
-            // stricter.  Behind the last tap of a conv everything is awaited: the SE image and the
-            // bias are read next.
-            if (AHEAD == 2 && tap < 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            // of the tap after it (AHEAD = 2), provided that tap exists and was requested above;
+            // bias / SE pieces in between only make the wait stricter.  Behind the last tap of a
+            // conv everything is awaited: the SE image and the bias are read next.
+            if (AHEAD == 2 && tap < 8 && T + AHEAD < total_taps) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else wait_weights();
             __syncthreads();  // next tap visible; everyone is done reading this buffer and, after tap 8, the activations
             if (tap + 1 < 9) {

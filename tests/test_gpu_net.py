@@ -112,6 +112,26 @@ def test_batch_4096_full_network():
         assert np.abs(v3.cpu().numpy() - value[sub[:count]]).max() < 1e-2
 
 
+@pytest.mark.parametrize("B", [8, 200, 400, 1024])
+def test_forward_is_reproducible_from_the_first_call(B):
+    """A cold first forward (weights not yet in any cache, LDS holding whatever ran before)
+    must give the same bits as every later one: catches a tap read before its copy landed
+    or any use of uninitialised scratch.  One batch size per form of the tower."""
+    from alphazero_amd.model import AlphaZeroNet, HipInference
+    torch.manual_seed(5)
+    model = AlphaZeroNet(num_blocks=20, num_filters=128).eval()
+    x = torch.from_numpy(_positions(B, seed=3)).cuda()
+    inf = HipInference(model, max_batch=max(16, B))
+    p0, v0, _, _ = inf.forward_planes(x)
+    p0, v0 = p0.clone(), v0.clone()
+    for _ in range(50):
+        p, v, _, _ = inf.forward_planes(x)
+        assert torch.equal(p, p0) and torch.equal(v, v0)
+    other = HipInference(model, max_batch=max(16, B))          # a second instance, cold again
+    p, v, _, _ = other.forward_planes(x)
+    assert torch.equal(p, p0) and torch.equal(v, v0)
+
+
 def test_matches_reference_logits_fixture(golden_dir):
     """nn_tier.npz holds logits produced by the reference's own AlphaZeroNet
     (torch.manual_seed(0), 20 x 128, BatchNorm statistics randomised with seed 1)."""

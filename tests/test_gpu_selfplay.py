@@ -135,3 +135,76 @@ def test_full_size_plies_keep_the_search_invariants():
     assert st["moves"] == 3 * nG and st["simulations"] == 3 * nG * S
     s, p, wl = e.drain_samples()
     assert len(s) == 0                                                    # no game has finished
+
+
+def test_fused_search_with_the_real_network_equals_the_oracle(small_model):
+    """The whole fused path (HIP network inside the library, 800 simulations, injected root
+    noise, tree reuse over two plies) against the CPU oracle driven with the same network's
+    outputs: identical visit counts, value sums and priors for every root."""
+    from alphazero_amd.engine import Engine
+    from alphazero_amd.model import HipInference
+    nG, S = 8, 800
+    inf = HipInference(small_model, max_batch=16)
+    w, b, t, win = orc.random_positions(900, seed=21)
+    idx = [i for i in range(900) if win[i] == 0 and orc.legal_actions(orc.make_pos(w[i], b[i], t[i])).size][:: 900 // nG][:nG]
+    dev = Engine(nG, pool_nodes_per_game=1 << 16)
+    dev.set_positions(np.arange(nG), w[idx], b[idx], t[idx])
+    dev.attach_net(inf)
+    cpu = orc.OracleMCTS(nG)
+    for j, i in enumerate(idx):
+        cpu.set_game(j, orc.make_pos(w[i], b[i], t[i]))
+    start = orc.encode_state(orc.start_position())
+
+    def evaluate(planes, need):
+        x = np.ascontiguousarray(planes, np.float32).copy()
+        x[np.asarray(need) == 0] = start                  # rows the oracle does not ask for: any valid state
+        probs, value, _, _ = inf.forward_planes(torch.from_numpy(x).cuda())
+        return probs.cpu().numpy().copy(), value.cpu().numpy().copy()
+
+    rs = np.random.RandomState(4)
+    alive = np.ones(nG, bool)
+    for ply in range(2):
+        dev.set_active(alive.astype(np.uint8)); cpu.set_active(alive)
+        noise = rs.dirichlet([0.35] * 48, size=nG)
+        dev.search(0, add_noise=False)                    # expands the roots that need it
+        dev.add_noise(noise)
+        dev.search(S, add_noise=False)
+        cpu.search(evaluate, S, noise=noise)
+        for g in range(nG):
+            if not alive[g]:
+                continue
+            a, o = dev.root_children(g), cpu.root_children(g)
+            assert np.array_equal(a["actions"], o["actions"])
+            assert np.array_equal(a["N"], o["N"]), (ply, g)
+            assert np.array_equal(a["W"].view(np.uint32), o["W"].view(np.uint32))
+            assert np.array_equal(a["P"].view(np.uint64), o["P"].view(np.uint64))
+        acts = np.full(nG, -1, np.int16)
+        for g in range(nG):
+            if alive[g]:
+                o = cpu.root_children(g)
+                acts[g] = int(o["actions"][np.argmax(o["N"])])
+                cpu.advance(g, int(acts[g]))
+                if orc.is_terminal(cpu.get_game(g)):
+                    alive[g] = False
+        dev.advance_all(acts)
+
+
+def test_selfplay_is_reproducible_for_a_seed(small_model):
+    """Two engines with the same seed play the same games (device RNG is counter-based);
+    another seed plays different ones."""
+    from alphazero_amd.selfplay import SelfPlay
+
+    def run(seed):
+        sp = SelfPlay(small_model, n_games=32, num_simulations=32, seed=seed, pool_nodes_per_game=1 << 14)
+        moves = []
+        for _ in range(12):
+            sp.step(restart_finished=True)
+            moves.append(sp.engine.chosen_actions().copy())
+        return np.stack(moves), [x.cpu().numpy() for x in sp.engine.drain_samples()]
+    a_moves, a_samples = run(9)
+    b_moves, b_samples = run(9)
+    c_moves, _ = run(10)
+    assert np.array_equal(a_moves, b_moves)
+    for x, y in zip(a_samples, b_samples):
+        assert np.array_equal(x, y)
+    assert not np.array_equal(a_moves, c_moves)
