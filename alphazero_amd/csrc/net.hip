@@ -1086,6 +1086,7 @@ struct az_net {
     unsigned long long* stamps = nullptr;  // diagnostic cycle stamps (AZ_TOWER_STAMPS=1)
     // optional HIP-event timing of the tower kernel (az_net_set_timing)
     bool timing = false;
+    int tower_form = 0;   // 0: chosen by batch size; 1, 2, 4, 8: forced (az_net_set_tower_form)
     int64_t launches = 0;
     int ev_used = 0;
     std::vector<hipEvent_t> ev0, ev1;
@@ -1118,6 +1119,13 @@ extern "C" int az_net_debug_stamps(az_net* n, unsigned long long* out_host, int3
 }
 
 extern "C" int az_net_max_batch(az_net* n) { return n ? n->max_batch : 0; }
+
+extern "C" int az_net_set_tower_form(az_net* n, int32_t form) {
+    AZ_CHECK_ARG(n, "az_net_set_tower_form: null network");
+    AZ_CHECK_ARG(form == 0 || form == 1 || form == 2 || form == 4 || form == 8, "az_net_set_tower_form: form %d is not one of 0, 1, 2, 4, 8", form);
+    n->tower_form = form;
+    return AZ_OK;
+}
 
 extern "C" int az_net_set_timing(az_net* n, int32_t enable) {
     AZ_CHECK_ARG(n, "az_net_set_timing: null network");
@@ -1358,8 +1366,9 @@ int az::net_forward_partial(az_net* n, int32_t B, const uint64_t* mine_dev, cons
     const bool stamp = n->timing && (n->launches++ % TIMING_STRIDE == 0) && n->ev_used < TIMING_POOL;
     if (stamp) AZ_HIP(hipEventRecord(n->ev0[n->ev_used], s));
     // form of the tower: whole positions per wave from 513 positions up, channel-split waves
-    // below (AZ_TOWER_FORM = 1, 2 or 4 forces one; the cycle stamps exist in the first only)
-    static const int forced = getenv("AZ_TOWER_FORM") ? atoi(getenv("AZ_TOWER_FORM")) : 0;
+    // below (az_net_set_tower_form or AZ_TOWER_FORM force one; the cycle stamps exist in k_tower only)
+    static const int env_form = getenv("AZ_TOWER_FORM") ? atoi(getenv("AZ_TOWER_FORM")) : 0;
+    const int forced = n->tower_form ? n->tower_form : env_form;
     int form = forced ? forced : (B <= 256 ? 1 : (B <= 512 ? 2 : 4));
     if (n->stamps || dbg) form = 4;
     if (form == 1) hipLaunchKernelGGL((k_tower_split<1, 4>), dim3(B), dim3(256), 0, s, tp);

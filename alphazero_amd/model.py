@@ -130,6 +130,10 @@ class HipInference:
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().az_net_load_state(self.h, C.c_void_p(blob.data_ptr()), blob.numel()))
 
+    def set_tower_form(self, form=0):
+        """0: by batch size; 1, 2, 4, 8: force that form of the tower kernel."""
+        _lib.check(_lib.lib().az_net_set_tower_form(self.h, int(form)))
+
     def set_timing(self, enable=True):
         _lib.check(_lib.lib().az_net_set_timing(self.h, int(bool(enable))))
 

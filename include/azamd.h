@@ -96,6 +96,11 @@ int az_net_forward_planes(az_net* n, int32_t B, const float* planes_dev, float* 
  * to 512 samples); az_net_tower_time waits for them, returns their mean
  * duration in milliseconds and the sample count, and clears the pool. */
 int az_net_set_timing(az_net* n, int32_t enable);
+/* Form of the tower kernel: 0 (default) chooses by batch size - one position per
+ * workgroup up to 256 positions, two up to 512, one position per wave above; 1, 2, 4
+ * force one of these, 8 the eight-wave channel-split form.  Every form computes the
+ * same network (src/model.py:144-180); they differ in how a batch spreads over the chip. */
+int az_net_set_tower_form(az_net* n, int32_t form);
 int az_net_tower_time(az_net* n, double* mean_ms, int64_t* samples);
 
 /* ------------------------------------------------------------------------

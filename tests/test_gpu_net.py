@@ -132,6 +132,41 @@ def test_forward_is_reproducible_from_the_first_call(B):
     assert torch.equal(p, p0) and torch.equal(v, v0)
 
 
+def test_every_tower_form_computes_the_same_network():
+    """Forms 1, 2, 4 and 8 of the tower on one batch: each within tolerance of the float32
+    torch forward, equal to one another up to summation order, and bit-reproducible."""
+    from alphazero_amd.model import AlphaZeroNet, HipInference
+    torch.manual_seed(2)
+    model = AlphaZeroNet(num_blocks=20, num_filters=128)
+    randomize_bn(model, 3)
+    model.eval()
+    planes = _positions(300, seed=12)
+    x = torch.from_numpy(planes)
+    with torch.no_grad():
+        pl, wl = model(x)
+    probs_ref = torch.softmax(pl, 1).numpy()
+    wlp = torch.softmax(wl, 1).numpy()
+    value_ref = wlp[:, 0] - wlp[:, 1]
+    inf = HipInference(model, max_batch=304)
+    out = {}
+    for form in (1, 2, 4, 8):
+        inf.set_tower_form(form)
+        p, v, _, _ = inf.forward_planes(x.cuda())
+        p, v = p.clone(), v.clone()
+        for _ in range(20):
+            p2, v2, _, _ = inf.forward_planes(x.cuda())
+            assert torch.equal(p2, p) and torch.equal(v2, v), form
+        out[form] = (p.cpu().numpy(), v.cpu().numpy())
+        assert np.abs(out[form][0] - probs_ref).max() <= TOL and np.abs(out[form][1] - value_ref).max() <= TOL
+    for form in (1, 2, 8):
+        assert np.abs(out[form][0] - out[4][0]).max() < 1e-3, form
+        assert np.abs(out[form][1] - out[4][1]).max() < 1e-2, form
+    inf.set_tower_form(0)
+    from alphazero_amd._lib import AzError
+    with pytest.raises(AzError):
+        inf.set_tower_form(3)
+
+
 def test_matches_reference_logits_fixture(golden_dir):
     """nn_tier.npz holds logits produced by the reference's own AlphaZeroNet
     (torch.manual_seed(0), 20 x 128, BatchNorm statistics randomised with seed 1)."""
