@@ -47,6 +47,10 @@ struct EngineView {
     // serialise 1024 atomics per simulation at the L2, ~12 us)
     unsigned long long *stat_depth, *stat_descents;
     unsigned long long *stat_terminal, *stat_rootexp;  // terminal leaves backed up, roots expanded
+    // Row of game g in the network's outputs (probabilities, values, head partial sums), or NULL
+    // when rows are games.  The fused search evaluates only the active games, packed densely,
+    // so that a shrinking set of games runs smaller, faster network launches.
+    const int32_t* row_of;
 };
 
 struct NodeQuery {
@@ -143,6 +147,8 @@ struct az_engine {
     bool sp_ready = false;
     float* nn_probs = nullptr;   // [B][192]
     float* nn_values = nullptr;  // [B]
+    int32_t* row_of_dev = nullptr;   // [B] row of each active game in the packed network batch
+    int32_t* game_of_dev = nullptr;  // [B] the inverse: game of each row
     uint64_t move_calls = 0;
 };
 

@@ -69,6 +69,7 @@ constexpr int VALUE_K = 64 * VALUE_CH;         // 2048
 struct TowerParams {
     const uint64_t* mine;       // [B] canonical bitboards
     const uint64_t* theirs;
+    const int32_t* gather;      // position i is mine[gather[i]] / theirs[gather[i]]; NULL: i itself
     int B;
     int blocks;
     const uint8_t* stem_w;      // [ks 2][nt 4][lane 64][16 B]
@@ -298,7 +299,8 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
 
     // ---------------- stem: 3x3 conv over the 3 input planes, K = 27 padded to 32
     {
-        const uint64_t mine = live ? p.mine[pos] : 0ull, theirs = live ? p.theirs[pos] : 0ull;
+        const int src_pos = (live && p.gather) ? p.gather[pos] : pos;
+        const uint64_t mine = live ? p.mine[src_pos] : 0ull, theirs = live ? p.theirs[src_pos] : 0ull;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -687,7 +689,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_tower_split(TowerParams p) {
 
     // ---------------- stem
     {
-        const uint64_t mine = live ? p.mine[pos] : 0ull, theirs = live ? p.theirs[pos] : 0ull;
+        const int src_pos = (live && p.gather) ? p.gather[pos] : pos;
+        const uint64_t mine = live ? p.mine[src_pos] : 0ull, theirs = live ? p.theirs[src_pos] : 0ull;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -1350,13 +1353,13 @@ extern "C" int az_net_load_state(az_net* n, const float* s, int64_t count) {
 
 // tower + head GEMMs: leaves the split-K partial sums in the network's buffers
 int az::net_forward_partial(az_net* n, int32_t B, const uint64_t* mine_dev, const uint64_t* theirs_dev,
-                            hipStream_t s) {
+                            const int32_t* gather_dev, hipStream_t s) {
     AZ_CHECK_ARG(n && n->loaded, "az_net_forward: network has no weights (call az_net_load_state)");
     AZ_CHECK_ARG(B >= 0 && B <= n->max_batch, "az_net_forward: batch %d exceeds max_batch %d", B, n->max_batch);
     if (B == 0) return AZ_OK;
     AZ_CHECK_ARG(mine_dev && theirs_dev, "az_net_forward: null pointer");
     TowerParams tp;
-    tp.mine = mine_dev; tp.theirs = theirs_dev; tp.B = B; tp.blocks = n->blocks;
+    tp.mine = mine_dev; tp.theirs = theirs_dev; tp.gather = gather_dev; tp.B = B; tp.blocks = n->blocks;
     tp.stem_w = n->stem_w; tp.stem_b = n->stem_b; tp.conv_w = n->conv_w; tp.conv_b = n->conv_b;
     tp.se_img = n->se_img;
     tp.value_w = n->value_w; tp.value_b = n->value_b; tp.p_act = n->p_act; tp.v_act = n->v_act;
@@ -1386,11 +1389,10 @@ az::FinishParams az::net_finish_params(az_net* n, int32_t B) {
     return FinishParams{n->part_p, n->part_v, n->bp, n->bv1, n->wv2, n->bv2, nullptr, nullptr, nullptr, nullptr, B};
 }
 
-extern "C" int az_net_forward(az_net* n, int32_t B, const uint64_t* mine_dev, const uint64_t* theirs_dev,
-                              float* probs_dev, float* value_dev, float* policy_logits_dev,
-                              float* wl_logits_dev, void* stream) {
-    hipStream_t s = (hipStream_t)stream;
-    const int rc = az::net_forward_partial(n, B, mine_dev, theirs_dev, s);
+int az::net_forward_full(az_net* n, int32_t B, const uint64_t* mine_dev, const uint64_t* theirs_dev,
+                         const int32_t* gather_dev, float* probs_dev, float* value_dev, float* policy_logits_dev,
+                         float* wl_logits_dev, hipStream_t s) {
+    const int rc = az::net_forward_partial(n, B, mine_dev, theirs_dev, gather_dev, s);
     if (rc != AZ_OK || B == 0) return rc;
     AZ_CHECK_ARG(probs_dev && value_dev, "az_net_forward: null pointer");
     FinishParams fp = az::net_finish_params(n, B);
@@ -1398,6 +1400,13 @@ extern "C" int az_net_forward(az_net* n, int32_t B, const uint64_t* mine_dev, co
     hipLaunchKernelGGL(k_head_finish, dim3((B + 3) / 4), dim3(256), 0, s, fp);
     AZ_HIP(hipGetLastError());
     return AZ_OK;
+}
+
+extern "C" int az_net_forward(az_net* n, int32_t B, const uint64_t* mine_dev, const uint64_t* theirs_dev,
+                              float* probs_dev, float* value_dev, float* policy_logits_dev,
+                              float* wl_logits_dev, void* stream) {
+    return az::net_forward_full(n, B, mine_dev, theirs_dev, nullptr, probs_dev, value_dev, policy_logits_dev,
+                                wl_logits_dev, (hipStream_t)stream);
 }
 
 extern "C" int az_net_forward_planes(az_net* n, int32_t B, const float* planes_dev, float* probs_dev,

@@ -174,7 +174,8 @@ __global__ __launch_bounds__(64) void k_tree_step(EngineView E, FinishParams F, 
     lf.node = E.leaf_node[g]; lf.mine = E.leaf_mine[g]; lf.theirs = E.leaf_theirs[g];
     lf.turn = E.leaf_turn[g]; lf.used = E.used[g];
     HeadOperands ho;
-    if (need) ho = head_load(F, g, lane);
+    const int row = E.row_of ? E.row_of[g] : g;
+    if (need) ho = head_load(F, row, lane);
     // ---- round 2
     const bool on_path = lane < len;
     const size_t my_node = pool + (on_path ? my_path : st.root);
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(64) void k_tree_step(EngineView E, FinishParams F, 
     Expansion ex{0, 0, lf.info};
     if (need) {
         float pr[3];
-        v = head_compute(F, ho, g, lane, pr);
+        v = head_compute(F, ho, row, lane, pr);
         s_probs[lane] = pr[0]; s_probs[lane + 64] = pr[1]; s_probs[lane + 128] = pr[2];
         __syncthreads();
         ex = dev_expand(E, g, lane, pool, lf, s_probs, s_p, s_a);
@@ -253,6 +254,7 @@ static int selfplay_alloc(az_engine* e) {
     AZ_ALLOC(S.q_wl, (size_t)S.q_cap * 2); AZ_ALLOC(S.q_pi, (size_t)S.q_cap * 192);
     AZ_ALLOC(S.q_count, 1); AZ_ALLOC(S.stat, 4);
     AZ_ALLOC(e->nn_probs, B * 192); AZ_ALLOC(e->nn_values, B);
+    AZ_ALLOC(e->row_of_dev, B); AZ_ALLOC(e->game_of_dev, B);
 #undef AZ_ALLOC
     e->sp_ready = true;
     return AZ_OK;
@@ -279,19 +281,45 @@ static int check_sticky(az_engine* e, hipStream_t s) {
 
 // MCTS.search_batch (src/mcts.py:94-189) with the attached network.  Per simulation
 // three launches: tower, head GEMMs, k_tree_step.
+// Packs the active games into rows 0 .. M-1 of the network batch.  Returns M; with every
+// game active rows are games and no index is used.
+static int pack_active_rows(az_engine* e, hipStream_t s, int* rows_out) {
+    const int B = e->v.B;
+    std::vector<uint8_t> active(B);
+    AZ_HIP(hipMemcpyAsync(active.data(), e->v.active, B, hipMemcpyDeviceToHost, s));
+    AZ_HIP(hipStreamSynchronize(s));
+    std::vector<int32_t> row_of(B, 0), game_of(B, 0);
+    int M = 0;
+    for (int g = 0; g < B; ++g)
+        if (active[g]) { row_of[g] = M; game_of[M] = g; ++M; }
+    *rows_out = M;
+    if (M == B || M == 0) { e->v.row_of = nullptr; return AZ_OK; }
+    AZ_HIP(hipMemcpyAsync(e->row_of_dev, row_of.data(), B * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    AZ_HIP(hipMemcpyAsync(e->game_of_dev, game_of.data(), B * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    AZ_HIP(hipStreamSynchronize(s));  // the host vectors go out of scope
+    e->v.row_of = e->row_of_dev;
+    return AZ_OK;
+}
+
 static int search_async(az_engine* e, int num_simulations, int add_noise, hipStream_t s) {
     if (!e->net) AZ_FAIL(AZ_ERR_STATE, "no network attached (az_engine_attach_net)");
     const int B = e->v.B;
-    int rc;
+    int rc, M = 0;
+    if ((rc = pack_active_rows(e, s, &M))) return rc;
+    if (M == 0) return AZ_OK;                       // no active game: nothing to search
+    const int32_t* gather = e->v.row_of ? e->game_of_dev : nullptr;
+    // every kernel launched below takes e->v by value, so the row index is dropped again
+    // before returning: the step API feeds per-game rows
+    struct Restore { az_engine* e; ~Restore() { e->v.row_of = nullptr; } } restore{e};
     if ((rc = az_engine_roots_prepare(e, nullptr, nullptr, s))) return rc;
-    if ((rc = az_net_forward(e->net, B, e->v.leaf_mine, e->v.leaf_theirs, e->nn_probs, e->nn_values, nullptr,
-                             nullptr, s))) return rc;
+    if ((rc = az::net_forward_full(e->net, M, e->v.leaf_mine, e->v.leaf_theirs, gather, e->nn_probs, e->nn_values,
+                                   nullptr, nullptr, s))) return rc;
     if ((rc = az_engine_roots_expand(e, e->nn_probs, s))) return rc;
     if (add_noise && (rc = az_engine_add_noise(e, nullptr, s))) return rc;
     if (num_simulations > 0 && (rc = az_engine_select(e, nullptr, nullptr, s))) return rc;
-    const FinishParams fin = az::net_finish_params(e->net, B);
+    const FinishParams fin = az::net_finish_params(e->net, M);
     for (int i = 0; i < num_simulations; ++i) {
-        if ((rc = az::net_forward_partial(e->net, B, e->v.leaf_mine, e->v.leaf_theirs, s))) return rc;
+        if ((rc = az::net_forward_partial(e->net, M, e->v.leaf_mine, e->v.leaf_theirs, gather, s))) return rc;
         hipLaunchKernelGGL(k_tree_step, dim3(B), dim3(64), 0, s, e->v, fin, i + 1 < num_simulations ? 1 : 0);
     }
     AZ_HIP(hipGetLastError());

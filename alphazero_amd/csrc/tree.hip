@@ -76,8 +76,9 @@ __global__ __launch_bounds__(64) void k_expand_backup(EngineView E, const float*
     const int g = blockIdx.x, lane = threadIdx.x;
     if (!E.active[g]) return;
     const int need = E.leaf_need[g];
-    if (need) dev_expand(E, g, lane, probs + (size_t)g * 192, s_p, s_a);
-    if (do_backup) dev_backup(E, g, lane, need ? values[g] : E.leaf_tv[g]);
+    const int row = E.row_of ? E.row_of[g] : g;
+    if (need) dev_expand(E, g, lane, probs + (size_t)row * 192, s_p, s_a);
+    if (do_backup) dev_backup(E, g, lane, need ? values[row] : E.leaf_tv[g]);
     if (lane == 0) E.leaf_need[g] = 0;
 }
 

@@ -208,3 +208,45 @@ def test_selfplay_is_reproducible_for_a_seed(small_model):
     for x, y in zip(a_samples, b_samples):
         assert np.array_equal(x, y)
     assert not np.array_equal(a_moves, c_moves)
+
+
+def test_fused_search_packs_the_active_games(small_model):
+    """With some games inactive the fused search evaluates only the active ones, packed into a
+    smaller network batch; the trees must equal those of the step API, which evaluates one
+    row per game, and inactive games must stay untouched."""
+    from alphazero_amd.engine import Engine
+    from alphazero_amd.model import HipInference
+    nG, S = 32, 64
+    inf = HipInference(small_model, max_batch=64)
+    w, b, t, win = orc.random_positions(600, seed=9)
+    idx = [i for i in range(600) if win[i] == 0][:: 600 // nG][:nG]
+    active = np.zeros(nG, np.uint8)
+    active[[0, 3, 4, 9, 17, 18, 19, 30, 31]] = 1
+    fused, step = Engine(nG, pool_nodes_per_game=1 << 15), Engine(nG, pool_nodes_per_game=1 << 15)
+    for e in (fused, step):
+        e.set_positions(np.arange(nG), w[idx], b[idx], t[idx])
+        e.set_active(active)
+    fused.attach_net(inf)
+    fused.search(S, add_noise=False)
+
+    start = torch.from_numpy(orc.encode_state(orc.start_position())).cuda()
+
+    def evaluate(planes, need):
+        x = planes.clone()
+        x[need == 0] = start             # rows nobody asks for (inactive games hold no planes): any valid state
+        probs, value, _, _ = inf.forward_planes(x)
+        return probs, value
+    step.search_with(evaluate, S)
+    for g in range(nG):
+        a, o = fused.root_children(g), step.root_children(g)
+        if not active[g]:
+            assert a is None and o is None
+            continue
+        assert np.array_equal(a["actions"], o["actions"])
+        assert np.array_equal(a["N"], o["N"])
+        assert np.array_equal(a["W"].view(np.uint32), o["W"].view(np.uint32))
+        assert np.array_equal(a["P"].view(np.uint64), o["P"].view(np.uint64))
+        assert a["root_N"] == S
+    active[:] = 0
+    fused.set_active(active)
+    fused.search(S)                      # nothing active: a no-op, not an error
