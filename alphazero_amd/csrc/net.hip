@@ -645,7 +645,15 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_tower_split(TowerParams p) {
         return slot < 2 ? (uint32_t)(LDS_W + slot * TAP_BYTES) : (uint32_t)ACT_REGION;
     };
     auto prefetch = [&](int T, int slot) {
-        if (WAVES == 4) {
+        if (NT == 1) {
+            // a wave copies exactly the fragments it reads itself (channel tile nt0 of every
+            // k-step, 1 KB each, 4 KB apart in the tap) into its own 8 KB of the buffer: the weight
+            // stream then needs no workgroup barrier at all
+            const uint8_t* src = p.conv_w + (size_t)T * TAP_BYTES + nt0 * 1024 + lane * 16;
+            const uint32_t dst = lds_base + tap_buffer(slot) + wave_u * 8192;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) glds16(src + ks * 4096, __builtin_amdgcn_readfirstlane(dst + ks * 1024));
+        } else if (WAVES == 4) {
             const uint8_t* src = p.conv_w + (size_t)T * TAP_BYTES + wave_u * 8192 + lane * 16;
             const uint32_t dst = lds_base + tap_buffer(slot) + wave_u * 8192;
             glds16x8(src + 4096, __builtin_amdgcn_readfirstlane(dst + 4096));
@@ -792,7 +800,9 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_tower_split(TowerParams p) {
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) w[ks][nt] = lds_read_frag(lds, wb + (ks * 4 + nt) * 1024);
+                for (int nt = 0; nt < NT; ++nt)
+                    w[ks][nt] = (NT == 1) ? lds_read_frag(lds, tap_buffer(slot) + wave_u * 8192 + lane * 16 + ks * 1024)
+                                          : lds_read_frag(lds, wb + (ks * 4 + nt) * 1024);
             if (tap + 1 < 9) {
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
@@ -813,7 +823,10 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_tower_split(TowerParams p) {
             // conv everything is awaited: the SE image and the bias are read next.
             if (AHEAD == 2 && tap < 8 && T + AHEAD < total_taps) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else wait_weights();
-            __syncthreads();  // next tap visible; everyone is done reading this buffer and, after tap 8, the activations
+            // NT = 2: next tap visible, everyone done reading this buffer.  NT = 1 reads only its own
+            // copies and meets the others after the last tap, when everyone is done reading the
+            // activations (and the bias / SE pieces copied by other waves have landed).
+            if (NT != 1 || tap == 8) __syncthreads();
             if (tap + 1 < 9) {
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) { xc[ks][0] = xn[ks][0]; xc[ks][1] = xn[ks][1]; }
