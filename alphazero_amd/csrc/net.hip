@@ -637,9 +637,9 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_tower_split(TowerParams p) {
     if (tid < 512 / 4) reinterpret_cast<uint32_t*>(lds + LDS_ZERO)[tid] = 0;
 
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_void*)lds;
-    // Weight taps: NT = 1 runs a tap in well under a microsecond, less than an L2 -> LDS copy
-    // takes, so it keeps three tap buffers (the third in an activation region it does not
-    // need) and copies two taps ahead; NT = 2 copies one tap ahead into two buffers.
+    // Weight taps: NT = 1 keeps three tap buffers (the third in an activation region it does
+    // not need), each wave owning a private quarter of each; NT = 2 copies one tap ahead into
+    // two shared buffers.
     constexpr int NBUF = (NT == 1) ? 3 : 2, AHEAD = NBUF - 1;
     auto tap_buffer = [&](int slot) -> uint32_t {  // slot = tap index modulo NBUF
         return slot < 2 ? (uint32_t)(LDS_W + slot * TAP_BYTES) : (uint32_t)ACT_REGION;
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_tower_split(TowerParams p) {
                    __builtin_amdgcn_readfirstlane(lds_base + LDS_SE + piece * 1024));
     };
 #pragma unroll
-    for (int t = 0; t < AHEAD; ++t) prefetch(t, t);
+    for (int t = 0; t < ((NT == 1) ? NBUF : AHEAD); ++t) prefetch(t, t);
     prefetch_bias(0);
 
     uint32_t aaddr[9][2];
@@ -736,6 +736,13 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_tower_split(TowerParams p) {
     wait_weights();
     __syncthreads();  // the first taps landed, zero row and every channel group's stem output visible
 
+    // NT = 1: weight fragments run one tap ahead of the MFMAs, like the activation fragments
+    bf16x8 wc1[8];
+    if constexpr (NT == 1) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) wc1[ks] = lds_read_frag(lds, tap_buffer(0) + wave_u * 8192 + lane * 16 + ks * 1024);
+    }
+
     for (int conv = 0; conv < nconv; ++conv) {
         {
             const float* b0 = reinterpret_cast<const float*>(lds + LDS_BIAS + (conv & 1) * 512) + h * 4;
@@ -765,6 +772,58 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_tower_split(TowerParams p) {
             const int T = conv * 9 + tap;
             // T modulo NBUF: 9 is a multiple of 3, and conv * 9 + tap has the parity of conv + tap
             const int slot = (NBUF == 3) ? tap % 3 : ((conv + tap) & 1);
+            if constexpr (NT == 1) {
+                // Registers hold the fragments of tap T.  One wave per SIMD feeds the matrix pipe, so
+                // everything else is issued between MFMAs.  Per k-step: the two MFMAs; the copy of
+                // the same 1 KB piece of tap T + 3 into the place the MFMAs just read (past the end of
+                // the network the last tap is copied again, into a buffer nobody reads any more, so
+                // that every tap issues the same 8 copies and the counted waits below hold
+                // everywhere); fragment reads of tap T + 1: activations under k-steps 0-3, weights
+                // under k-steps 4-7.  Tap T + 1 has landed when at most the copies issued after it are
+                // in flight: the 8 of tap T + 2 and the 4 of tap T + 3 issued so far (bias / SE pieces
+                // in between only make the wait stricter).
+                bf16x8 wn1[8], xn1[8][2];
+                const uint32_t wb1 = tap_buffer((tap + 1) % 3) + wave_u * 8192 + lane * 16;
+                const int T3 = (T + 3 < total_taps) ? T + 3 : total_taps - 1;
+                const uint8_t* src3 = p.conv_w + (size_t)T3 * TAP_BYTES + nt0 * 1024 + lane * 16;
+                const uint32_t dst3 = lds_base + tap_buffer(slot) + wave_u * 8192;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc1[ks], xc[ks][0], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc1[ks], xc[ks][1], acc[0][1], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ks == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                    glds16(src3 + ks * 4096, __builtin_amdgcn_readfirstlane(dst3 + ks * 1024));
+                    if (ks < 4) {
+                        if (tap + 1 < 9) {
+#pragma unroll
+                            for (int j = 2 * ks; j < 2 * ks + 2; ++j) {
+                                xn1[j][0] = lds_read_frag(lds, aaddr[tap + 1 < 9 ? tap + 1 : 0][0] + j * 32);
+                                xn1[j][1] = lds_read_frag(lds, aaddr[tap + 1 < 9 ? tap + 1 : 0][1] + j * 32);
+                            }
+                        }
+                    } else {
+                        wn1[2 * (ks - 4)] = lds_read_frag(lds, wb1 + (2 * (ks - 4)) * 1024);      // stale past the last tap, unused
+                        wn1[2 * (ks - 4) + 1] = lds_read_frag(lds, wb1 + (2 * (ks - 4) + 1) * 1024);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (tap == 0 && conv + 1 < nconv) prefetch_bias(conv + 1);
+                if ((conv & 1) && tap < 7 && conv < nconv - 1) prefetch_se(conv >> 1, tap * WAVES + wave_u);
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) wc1[ks] = wn1[ks];
+                if (tap + 1 < 9) {
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) { xc[ks][0] = xn1[ks][0]; xc[ks][1] = xn1[ks][1]; }
+                } else {
+                    // End of the conv: the SE image and the next bias (copied by other waves too) must
+                    // have landed, and every wave must be done reading the activations.  Only the 16
+                    // weight copies of taps 7 and 8 are younger than those pieces.
+                    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                    __syncthreads();
+                }
+                continue;
+            }
             if (T + AHEAD < total_taps) prefetch(T + AHEAD, (NBUF == 3) ? (tap + AHEAD) % 3 : (slot ^ 1));
             if (tap == 0 && conv + 1 < nconv) prefetch_bias(conv + 1);
             if ((conv & 1) && tap < 7 && conv < nconv - 1) prefetch_se(conv >> 1, tap * WAVES + wave_u);
@@ -878,21 +937,30 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_tower_split(TowerParams p) {
                     if (r < 16) scratch[ch] = tot * (1.0f / 64.0f);
                 }
             }
+            // the SE weights this lane needs are requested before the barrier: only the means and
+            // the hidden layer are then on the critical path behind it
+            const int j1 = lane & 15, q4 = lane >> 4;
+            f32x4 w1v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w1v[i] = *reinterpret_cast<const f32x4*>(se + j1 * SE_W1_PITCH + q4 * 32 + i * 4);
+            const float b1v = se[SE_OFF_B1 + j1];
+            float w2v[NT][17];
+#pragma unroll
+            for (int m = 0; m < NT; ++m)
+#pragma unroll
+                for (int jj = 0; jj < 17; ++jj) w2v[m][jj] = se[SE_OFF_W2 + h * CH + (nt0 + m) * 32 + r + jj * 256];
             __syncthreads();  // the means of every channel group
             // fc1 (128 -> 16) + ReLU, by every wave of the position for itself
             {
-                const int j = lane & 15, q4 = lane >> 4;
-                const float* w1 = se + j * SE_W1_PITCH + q4 * 32;
                 float y = 0.f;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(w1 + i * 4);
                     const f32x4 m = *reinterpret_cast<const f32x4*>(scratch + q4 * 32 + i * 4);
-                    y += w[0] * m[0] + w[1] * m[1] + w[2] * m[2] + w[3] * m[3];
+                    y += w1v[i][0] * m[0] + w1v[i][1] * m[1] + w1v[i][2] * m[2] + w1v[i][3] * m[3];
                 }
                 y += __shfl_xor(y, 16);
                 y += __shfl_xor(y, 32);
-                y = fmaxf(y + se[SE_OFF_B1 + j], 0.f);
+                y = fmaxf(y + b1v, 0.f);
                 if (lane < 16) scratch[128 + cw * 16 + lane] = y;
             }
             wave_lds_sync();
@@ -904,13 +972,9 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_tower_split(TowerParams p) {
 #pragma unroll
                 for (int m = 0; m < NT; ++m) {
                     const int col = h * CH + (nt0 + m) * 32 + r;
-                    const float* w2c = se + SE_OFF_W2 + col;
-                    float wv[17];
+                    float g = w2v[m][16];
 #pragma unroll
-                    for (int jj = 0; jj < 17; ++jj) wv[jj] = w2c[jj * 256];
-                    float g = wv[16];
-#pragma unroll
-                    for (int jj = 0; jj < 16; ++jj) g += wv[jj] * hid[jj >> 2][jj & 3];
+                    for (int jj = 0; jj < 16; ++jj) g += w2v[m][jj] * hid[jj >> 2][jj & 3];
                     const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-g));
                     scratch[192 + col] = h ? g : sg;
                 }
@@ -971,6 +1035,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_tower_split(TowerParams p) {
             }
         }
     }
+    wait_weights();  // no copy into LDS may outlive the workgroup
 }
 
 // ---------------------------------------------------------------------------
