@@ -179,6 +179,33 @@ __device__ __forceinline__ void glds16x8(const void* gsrc_plus_4k, uint32_t lds_
         : "v"(gsrc_plus_4k), "s"(lds_dst_plus_4k)
         : "memory");
 }
+// the two halves of glds16x8 (same bases), for callers that spread the copy over an MFMA stream
+__device__ __forceinline__ void glds16x4_lo(const void* gsrc_plus_4k, uint32_t lds_dst_plus_4k) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off offset:-4096\n\t"
+        "global_load_lds_dwordx4 %1, off offset:-3072\n\t"
+        "global_load_lds_dwordx4 %1, off offset:-2048\n\t"
+        "global_load_lds_dwordx4 %1, off offset:-1024\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc_plus_4k), "s"(lds_dst_plus_4k)
+        : "memory");
+}
+__device__ __forceinline__ void glds16x4_hi(const void* gsrc_plus_4k, uint32_t lds_dst_plus_4k) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+        "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+        "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc_plus_4k), "s"(lds_dst_plus_4k)
+        : "memory");
+}
 __device__ __forceinline__ void wait_weights() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 struct Frags {
@@ -263,6 +290,12 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
         const uint8_t* src = p.conv_w + (size_t)T * TAP_BYTES + wave_u * 8192 + lane * 16;
         const uint32_t dst = lds_base + LDS_W + (T & 1) * TAP_BYTES + wave_u * 8192;
         glds16x8(src + 4096, __builtin_amdgcn_readfirstlane(dst + 4096));
+    };
+    auto prefetch_half = [&](int T, int half) {
+        const uint8_t* src = p.conv_w + (size_t)T * TAP_BYTES + wave_u * 8192 + lane * 16;
+        const uint32_t dst = lds_base + LDS_W + (T & 1) * TAP_BYTES + wave_u * 8192;
+        if (half == 0) glds16x4_lo(src + 4096, __builtin_amdgcn_readfirstlane(dst + 4096));
+        else glds16x4_hi(src + 4096, __builtin_amdgcn_readfirstlane(dst + 4096));
     };
     // folded-BN bias of conv c -> LDS bias buffer c&1 (waves 0 and 1, 256 B each)
     auto prefetch_bias = [&](int c) {
@@ -362,9 +395,6 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int T = conv * 9 + tap;
-            if (T + 1 < total_taps) prefetch(T + 1);
-            if (tap == 0 && conv + 1 < nconv) prefetch_bias(conv + 1);
-            if ((conv & 1) && tap < 7 && conv < nconv - 1) prefetch_se(conv >> 1, tap * 4 + wave_u);
             const uint32_t wb = LDS_W + (T & 1) * TAP_BYTES + lane * 16;
             const uint32_t wb_next = LDS_W + ((T + 1) & 1) * TAP_BYTES + lane * 16;
 #pragma unroll
@@ -372,8 +402,35 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
                 // one pipeline step = 6 fragment reads (for the step after) + 8 MFMAs; the reads
                 // are spread one per MFMA so that each issues in an MFMA's shadow
                 load_frags(f1, lds, aaddr[tap][0], aaddr[tap][1], wb, ks + 1);
-                mma_step(acc, f0);
-                interleave_step();
+                if (ks == 0) {
+                    // The first step of a tap also carries the copy of the next tap (its buffer was
+                    // released by the barrier inside the previous tap) and the bias / SE pieces, in
+                    // three groups between MFMA pairs: this wave is its SIMD's only source of MFMAs,
+                    // whatever is issued outside the stream leaves the matrix pipe idle.
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0.w[nt], f0.x[0], acc[nt][0], 0, 0, 0);
+                        acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0.w[nt], f0.x[1], acc[nt][1], 0, 0, 0);
+                        if (nt < 3) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        } else {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (nt < 2) {
+                            if (T + 1 < total_taps) prefetch_half(T + 1, nt);
+                        } else if (nt == 2) {
+                            if (tap == 0 && conv + 1 < nconv) prefetch_bias(conv + 1);
+                            if ((conv & 1) && tap < 7 && conv < nconv - 1) prefetch_se(conv >> 1, tap * 4 + wave_u);
+                        }
+                    }
+                } else {
+                    mma_step(acc, f0);
+                    interleave_step();
+                }
                 if (ks + 2 < 8) {
                     load_frags(f0, lds, aaddr[tap][0], aaddr[tap][1], wb, ks + 2);
                     mma_step(acc, f1);
