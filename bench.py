@@ -131,8 +131,12 @@ def main():
     st0 = eng.stats()
     inf.set_timing(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         sp.step(restart_finished=True)
+        # long runs: hand the finished games' samples over before the device queue fills
+        # (on the device, as a trainer would take them; part of the timed work)
+        if (i + 1) % 16 == 0 and eng.samples_pending() > 32768:
+            eng.drain_samples()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     tower_ms, tower_samples = inf.tower_time()
