@@ -80,6 +80,7 @@ _SIGNATURES = {
     "az_net_forward_planes": [_VP, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP],
     "az_net_set_timing": [_VP, C.c_int32],
     "az_net_set_tower_form": [_VP, C.c_int32],
+    "az_net_debug_stamps": [_VP, _VP, C.c_int32],
     "az_net_tower_time": [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
     "az_engine_attach_net": [_VP, _VP],
     "az_engine_search": [_VP, C.c_int32, C.c_int32, _VP],

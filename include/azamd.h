@@ -102,6 +102,11 @@ int az_net_set_timing(az_net* n, int32_t enable);
  * same network (src/model.py:144-180); they differ in how a batch spreads over the chip. */
 int az_net_set_tower_form(az_net* n, int32_t form);
 int az_net_tower_time(az_net* n, double* mean_ms, int64_t* samples);
+/* Measurement aid (no reference counterpart): with AZ_TOWER_STAMPS=1 in the environment at
+ * az_net_create, the one-position-per-wave tower records per workgroup ten 64-bit counters
+ * (cycles in conv loops / conv epilogues / block epilogues, 100 MHz ticks, four parts of the
+ * block epilogue, first and last tick); this copies workgroups x 10 of them to the host. */
+int az_net_debug_stamps(az_net* n, unsigned long long* out_host, int32_t workgroups);
 
 /* ------------------------------------------------------------------------
  * Search engine: B independent games, one tree each, nodes in an SoA pool in
