@@ -253,6 +253,53 @@ def make_tree_tier():
     print("tree tier done")
 
 
+# ------------------------------------------------------------------ wide tree tier
+def make_tree_wide_tier():
+    """64 root positions from seeded random play at every stage of the game (both colours,
+    down to a handful of pieces), one fresh search each without noise (S = 200) and one with
+    recorded Dirichlet draws (S = 120)."""
+    rng = random.Random(2025)
+    roots_pos = []
+    while len(roots_pos) < 64:
+        g = BreakthroughGame()
+        stop = rng.randrange(0, 75)
+        for _ in range(stop):
+            if g.is_terminal():
+                break
+            g.step(rng.choice(g.get_legal_moves()))
+        if not g.is_terminal():
+            roots_pos.append(g)
+    out = {}
+    wb = [game_bits(g) for g in roots_pos]
+    out["white"] = np.array([x[0] for x in wb], np.uint64)
+    out["black"] = np.array([x[1] for x in wb], np.uint64)
+    out["turn"] = np.array([g.turn for g in roots_pos], np.int8)
+    for tag, S, noisy in (("plain", 200, False), ("noise", 120, True)):
+        m = TableMCTS(None, num_simulations=S, c_puct=1.5)
+        drawn = []
+        orig = np.random.dirichlet
+
+        def rec(alpha, *a, **k):
+            v = orig(alpha, *a, **k)
+            drawn.append(np.concatenate([v, np.zeros(48 - len(v))]))
+            return v
+        np.random.seed(4242)
+        np.random.dirichlet = rec
+        try:
+            roots = m.search_batch([g.clone() for g in roots_pos], None, add_noise=noisy)
+        finally:
+            np.random.dirichlet = orig
+        st = [root_stats(r) for r in roots]
+        for key in st[0]:
+            out[f"{tag}_{key}"] = np.array([s[key] for s in st])
+        out[f"{tag}_sims"] = np.array(S)
+        if noisy:
+            assert len(drawn) == len(roots_pos)
+            out[f"{tag}_draws"] = np.array(drawn, np.float64)
+    np.savez_compressed(os.path.join(HERE, "tree_wide_tier.npz"), **out)
+    print("wide tree tier:", len(roots_pos), "positions, turns", int((out["turn"] > 0).sum()), "white to move")
+
+
 # ------------------------------------------------------------------ self-play tier
 def make_selfplay_tier():
     nG, S = 3, 30
@@ -395,6 +442,7 @@ def make_train_tier():
 if __name__ == "__main__":
     torch.set_num_threads(4)
     tiers = {"table": make_table, "game": make_game_tier, "tree": make_tree_tier,
+             "tree_wide": make_tree_wide_tier,
              "selfplay": make_selfplay_tier, "nn": make_nn_tier, "train": make_train_tier}
     for name in (sys.argv[1:] or list(tiers)):
         tiers[name]()

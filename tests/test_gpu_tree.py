@@ -145,3 +145,20 @@ def test_batched_root_queries_and_reroots_equal_single_calls():
     ea.set_roots([2], [int(ea.pool_usage()[2]) + 5])
     with pytest.raises(AzError):
         ea.pool_usage()
+
+
+@pytest.mark.parametrize("tag", ["plain", "noise"])
+def test_wide_positions_match_reference(golden_dir, tag):
+    """64 roots from every stage of the game, searched once by the device engine: children,
+    visits, value sums and priors equal the reference's (tree_wide_tier.npz)."""
+    from gpu_backend import EngineBackend
+    d = np.load(os.path.join(golden_dir, "tree_wide_tier.npz"))
+    nG = len(d["white"])
+    m = EngineBackend(nG, pool_nodes_per_game=1 << 14)
+    for g in range(nG):
+        m.set_game(g, orc.make_pos(d["white"][g], d["black"][g], d["turn"][g]))
+    m.set_active(np.ones(nG, np.uint8))
+    noise = d["noise_draws"] if tag == "noise" else None
+    m.search(TableEvaluator(), int(d[f"{tag}_sims"]), noise=noise)
+    for g in range(nG):
+        _check_children(m.root_children(g), d, tag, g)

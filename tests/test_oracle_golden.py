@@ -140,3 +140,18 @@ def test_selfplay_stream_bit_exact(golden_dir):
     assert np.array_equal(np.array(states), ref_states)
     assert np.array_equal(np.array(policies).view(np.uint32), d["policies"].view(np.uint32))
     assert np.array_equal(np.array(wls), d["wls"])
+
+
+@pytest.mark.parametrize("tag", ["plain", "noise"])
+def test_tree_wide_positions_bit_exact(golden_dir, tag):
+    """64 roots from every stage of the game (tree_wide_tier.npz): one search each, without noise
+    and with the reference's recorded Dirichlet draws."""
+    d = np.load(os.path.join(golden_dir, "tree_wide_tier.npz"))
+    nG = len(d["white"])
+    m = orc.OracleMCTS(nG, c_puct=1.5)
+    for g in range(nG):
+        m.set_game(g, orc.make_pos(d["white"][g], d["black"][g], d["turn"][g]))
+    noise = d["noise_draws"] if tag == "noise" else None
+    m.search(TableEvaluator(), int(d[f"{tag}_sims"]), noise=noise)
+    for g in range(nG):
+        _check_children(m.root_children(g), d, tag, g)
