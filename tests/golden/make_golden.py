@@ -301,8 +301,7 @@ def make_tree_wide_tier():
 
 
 # ------------------------------------------------------------------ self-play tier
-def make_selfplay_tier():
-    nG, S = 3, 30
+def make_selfplay_tier(nG=3, S=30, seed=31337, name="selfplay_tier.npz"):
     tmp = tempfile.mkdtemp()
     model = AlphaZeroNet(num_blocks=1, num_filters=8)
     tr = ref_pt.ParallelTrainer(model, device="cpu", num_parallel_games=nG, num_simulations=S,
@@ -320,21 +319,26 @@ def make_selfplay_tier():
         v = oc(n, *a, **k)
         choice_draws.append(int(v))
         return v
-    np.random.seed(31337)
+    np.random.seed(seed)
     np.random.dirichlet, np.random.choice = rd, rc
     try:
         examples = tr.execute_parallel_episodes(nG)
     finally:
         np.random.dirichlet, np.random.choice = od, oc
     np.savez_compressed(
-        os.path.join(HERE, "selfplay_tier.npz"),
+        os.path.join(HERE, name),
         n_games=np.array(nG), sims=np.array(S),
         dirichlet=np.array(dir_draws, np.float64), choices=np.array(choice_draws, np.int16),
         states=np.packbits(np.array([e[0] for e in examples]) > 0.5, axis=None),
         n_examples=np.array(len(examples)),
         policies=np.array([e[1] for e in examples], np.float32),
         wls=np.array([e[2] for e in examples], np.float32))
-    print("selfplay tier:", len(examples), "examples,", len(choice_draws), "moves")
+    print(name, ":", len(examples), "examples,", len(choice_draws), "moves")
+
+
+def make_selfplay_wide_tier():
+    """16 complete games at 24 simulations: more finishing orders, more temperature-0 plies."""
+    make_selfplay_tier(nG=16, S=24, seed=777, name="selfplay_wide_tier.npz")
 
 
 # ------------------------------------------------------------------ NN tier
@@ -443,6 +447,6 @@ if __name__ == "__main__":
     torch.set_num_threads(4)
     tiers = {"table": make_table, "game": make_game_tier, "tree": make_tree_tier,
              "tree_wide": make_tree_wide_tier,
-             "selfplay": make_selfplay_tier, "nn": make_nn_tier, "train": make_train_tier}
+             "selfplay": make_selfplay_tier, "selfplay_wide": make_selfplay_wide_tier, "nn": make_nn_tier, "train": make_train_tier}
     for name in (sys.argv[1:] or list(tiers)):
         tiers[name]()

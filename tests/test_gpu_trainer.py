@@ -12,12 +12,13 @@ from test_gpu_dropin import _table_mcts
 pytestmark = pytest.mark.gpu
 
 
-def test_host_loop_reproduces_reference_examples(golden_dir, tmp_path, monkeypatch):
+@pytest.mark.parametrize("fixture", ["selfplay_tier.npz", "selfplay_wide_tier.npz"])
+def test_host_loop_reproduces_reference_examples(golden_dir, tmp_path, monkeypatch, fixture):
     """execute_parallel_episodes of the reference with a table network and recorded
     numpy draws (tests/golden/make_golden.py selfplay): same examples, same order."""
     from alphazero_amd.model import AlphaZeroNet
     from alphazero_amd.parallel_trainer import ParallelTrainer
-    d = np.load(os.path.join(golden_dir, "selfplay_tier.npz"))
+    d = np.load(os.path.join(golden_dir, fixture))
     n_games, sims = int(d["n_games"]), int(d["sims"])
     tr = ParallelTrainer(AlphaZeroNet(num_blocks=1, num_filters=8), device="cuda", num_parallel_games=n_games,
                          num_simulations=sims, checkpoint_dir=str(tmp_path), verbose=False)

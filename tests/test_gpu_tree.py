@@ -59,10 +59,11 @@ def test_reuse_sequence_matches_reference(tree_tier, tag):
                 alive[j] = False
 
 
-def test_selfplay_stream_matches_reference(golden_dir):
+@pytest.mark.parametrize("fixture", ["selfplay_tier.npz", "selfplay_wide_tier.npz"])
+def test_selfplay_stream_matches_reference(golden_dir, fixture):
     from gpu_backend import EngineBackend
     from selfplay_replay import replay_selfplay
-    d = np.load(os.path.join(golden_dir, "selfplay_tier.npz"))
+    d = np.load(os.path.join(golden_dir, fixture))
     nG, S = int(d["n_games"]), int(d["sims"])
     states, policies, wls = replay_selfplay(EngineBackend(nG, pool_nodes_per_game=1 << 16), nG, S,
                                             d["dirichlet"], d["choices"], TableEvaluator())

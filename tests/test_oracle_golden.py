@@ -127,10 +127,11 @@ def test_tree_reuse_sequence_bit_exact(tree_tier, tag):
         assert saw64
 
 
-def test_selfplay_stream_bit_exact(golden_dir):
+@pytest.mark.parametrize("fixture", ["selfplay_tier.npz", "selfplay_wide_tier.npz"])
+def test_selfplay_stream_bit_exact(golden_dir, fixture):
     """execute_parallel_episodes (parallel_trainer.py:137-223) replayed with the
     recorded Dirichlet draws and sampled actions."""
-    d = np.load(os.path.join(golden_dir, "selfplay_tier.npz"))
+    d = np.load(os.path.join(golden_dir, fixture))
     from selfplay_replay import replay_selfplay_oracle
     states, policies, wls = replay_selfplay_oracle(
         int(d["n_games"]), int(d["sims"]), d["dirichlet"], d["choices"], TableEvaluator())
