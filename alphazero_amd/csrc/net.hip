@@ -312,7 +312,10 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
     prefetch(0);
     prefetch_bias(0);
 
-    // per-tap fragment addresses (bytes from the LDS base) for the two pixel tiles
+    // per-tap fragment addresses (bytes from the LDS base) for the two pixel tiles.  An
+    // out-of-board pixel reads zeros from the 512-byte zero area, at the offset that falls on the
+    // same LDS banks as the pixel's own row would (272 = 16 mod 256): the lanes of a fragment read
+    // then still cover distinct banks
     uint32_t aaddr[9][2];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
             const int y = (px >> 3) + dy, x = (px & 7) + dx;
             const bool ok = (y >= 0) && (y < 8) && (x >= 0) && (x < 8);
             aaddr[tap][pt] = ok ? (uint32_t)(wave * ACT_REGION + (y * 8 + x) * ACT_PITCH + h * 16)
-                                : (uint32_t)(LDS_ZERO + h * 16);
+                                : (uint32_t)(LDS_ZERO + (((y * 8 + x) & 15) * 16 + h * 16));  // the banks the pixel would have had
         }
     }
 
@@ -745,7 +748,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_tower_split(TowerParams p) {
             const int y = (px >> 3) + dy, x = (px & 7) + dx;
             const bool ok = (y >= 0) && (y < 8) && (x >= 0) && (x < 8);
             aaddr[tap][pt] = ok ? (uint32_t)(lp * ACT_REGION + (y * 8 + x) * ACT_PITCH + h * 16)
-                                : (uint32_t)(LDS_ZERO + h * 16);
+                                : (uint32_t)(LDS_ZERO + (((y * 8 + x) & 15) * 16 + h * 16));  // the banks the pixel would have had
         }
     }
 
