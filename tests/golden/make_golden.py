@@ -300,6 +300,47 @@ def make_tree_wide_tier():
     print("wide tree tier:", len(roots_pos), "positions, turns", int((out["turn"] > 0).sum()), "white to move")
 
 
+# ------------------------------------------------------------------ exploration-constant tier
+CPUCT_CASES = (("c07", 0.7, 150, False), ("c21", 2.1, 150, False), ("c40", 4.0, 150, False),
+               ("c21n", 2.1, 90, True))
+
+
+def make_tree_cpuct_tier():
+    """The tree tier's ten roots searched with exploration constants other than 1.5, two of
+    them not representable in float32 (0.7, 2.1): pins where the constant is rounded."""
+    roots_pos = tree_positions()
+    out = {}
+    wb = [game_bits(g) for g in roots_pos]
+    out["white"] = np.array([x[0] for x in wb], np.uint64)
+    out["black"] = np.array([x[1] for x in wb], np.uint64)
+    out["turn"] = np.array([g.turn for g in roots_pos], np.int8)
+    out["tags"] = np.array([c[0] for c in CPUCT_CASES])
+    for tag, c, S, noisy in CPUCT_CASES:
+        m = TableMCTS(None, num_simulations=S, c_puct=c)
+        drawn = []
+        orig = np.random.dirichlet
+
+        def rec(alpha, *a, **k):
+            v = orig(alpha, *a, **k)
+            drawn.append(np.concatenate([v, np.zeros(48 - len(v))]))
+            return v
+        np.random.seed(97)
+        np.random.dirichlet = rec
+        try:
+            roots = m.search_batch([g.clone() for g in roots_pos], None, add_noise=noisy)
+        finally:
+            np.random.dirichlet = orig
+        st = [root_stats(r) for r in roots]
+        for key in st[0]:
+            out[f"{tag}_{key}"] = np.array([s[key] for s in st])
+        out[f"{tag}_sims"] = np.array(S)
+        out[f"{tag}_c_puct"] = np.array(c, np.float64)
+        if noisy:
+            out[f"{tag}_draws"] = np.array(drawn, np.float64)
+    np.savez_compressed(os.path.join(HERE, "tree_cpuct_tier.npz"), **out)
+    print("c_puct tier done")
+
+
 # ------------------------------------------------------------------ self-play tier
 def make_selfplay_tier(nG=3, S=30, seed=31337, name="selfplay_tier.npz"):
     tmp = tempfile.mkdtemp()
@@ -446,7 +487,7 @@ def make_train_tier():
 if __name__ == "__main__":
     torch.set_num_threads(4)
     tiers = {"table": make_table, "game": make_game_tier, "tree": make_tree_tier,
-             "tree_wide": make_tree_wide_tier,
+             "tree_wide": make_tree_wide_tier, "tree_cpuct": make_tree_cpuct_tier,
              "selfplay": make_selfplay_tier, "selfplay_wide": make_selfplay_wide_tier, "nn": make_nn_tier, "train": make_train_tier}
     for name in (sys.argv[1:] or list(tiers)):
         tiers[name]()

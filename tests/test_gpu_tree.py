@@ -163,3 +163,19 @@ def test_wide_positions_match_reference(golden_dir, tag):
     m.search(TableEvaluator(), int(d[f"{tag}_sims"]), noise=noise)
     for g in range(nG):
         _check_children(m.root_children(g), d, tag, g)
+
+
+@pytest.mark.parametrize("tag", ["c07", "c21", "c40", "c21n"])
+def test_other_exploration_constants_match_reference(golden_dir, tag):
+    """Exploration constants 0.7, 2.1 and 4.0 on the device engine (tree_cpuct_tier.npz)."""
+    from gpu_backend import EngineBackend
+    d = np.load(os.path.join(golden_dir, "tree_cpuct_tier.npz"))
+    nG = len(d["white"])
+    m = EngineBackend(nG, c_puct=float(d[f"{tag}_c_puct"]), pool_nodes_per_game=1 << 14)
+    for g in range(nG):
+        m.set_game(g, orc.make_pos(d["white"][g], d["black"][g], d["turn"][g]))
+    m.set_active(np.ones(nG, np.uint8))
+    noise = d[f"{tag}_draws"] if f"{tag}_draws" in d else None
+    m.search(TableEvaluator(), int(d[f"{tag}_sims"]), noise=noise)
+    for g in range(nG):
+        _check_children(m.root_children(g), d, tag, g)

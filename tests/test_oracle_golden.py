@@ -156,3 +156,19 @@ def test_tree_wide_positions_bit_exact(golden_dir, tag):
     m.search(TableEvaluator(), int(d[f"{tag}_sims"]), noise=noise)
     for g in range(nG):
         _check_children(m.root_children(g), d, tag, g)
+
+
+@pytest.mark.parametrize("tag", ["c07", "c21", "c40", "c21n"])
+def test_tree_other_exploration_constants_bit_exact(golden_dir, tag):
+    """Exploration constants 0.7, 2.1 and 4.0 (tree_cpuct_tier.npz): 0.7 and 2.1 have no exact
+    float32 form, so this pins that the constant enters the score rounded to float32
+    (src/mcts.py:304 multiplies a Python float into a float32 prior)."""
+    d = np.load(os.path.join(golden_dir, "tree_cpuct_tier.npz"))
+    nG = len(d["white"])
+    m = orc.OracleMCTS(nG, c_puct=float(d[f"{tag}_c_puct"]))
+    for g in range(nG):
+        m.set_game(g, orc.make_pos(d["white"][g], d["black"][g], d["turn"][g]))
+    noise = d[f"{tag}_draws"] if f"{tag}_draws" in d else None
+    m.search(TableEvaluator(), int(d[f"{tag}_sims"]), noise=noise)
+    for g in range(nG):
+        _check_children(m.root_children(g), d, tag, g)
