@@ -146,7 +146,7 @@ __global__ void k_unpack_samples(SelfplayView S, uint32_t n, float* states, floa
 // simulation's PUCT descent (src/mcts.py:153-187).
 //
 // The kernel is a chain of dependent memory round trips, so every load whose address is
-// known is issued up front, in three rounds: (1) the game's scalars, the recorded path and
+// known is issued up front, in three stages: (1) the game's scalars, the recorded path and
 // the head partial sums; (2) the root's fields and the visit/value words of the path nodes;
 // (3) the root's child statistics.  Expansion and backup then only store, and the next
 // descent starts from registers patched with those stores; its first memory round trip
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(64) void k_tree_step(EngineView E, FinishParams F, 
     __shared__ float s_p[MAX_CHILDREN];
     __shared__ uint8_t s_a[MAX_CHILDREN];
     const int g = blockIdx.x, lane = threadIdx.x;
-    // ---- round 1
+    // ---- load stage 1
     const int active = E.active[g];
     const int need = E.leaf_need[g];
     float v = E.leaf_tv[g];
@@ -176,14 +176,14 @@ __global__ __launch_bounds__(64) void k_tree_step(EngineView E, FinishParams F, 
     HeadOperands ho;
     const int row = E.row_of ? E.row_of[g] : g;
     if (need) ho = head_load(F, row, lane);
-    // ---- round 2
+    // ---- load stage 2
     const bool on_path = lane < len;
     const size_t my_node = pool + (on_path ? my_path : st.root);
     uint32_t bN = E.N[my_node];
     float bW = E.W[my_node];
     lf.info = E.IN[pool + lf.node];
     pre.inf = E.IN[pool + st.root]; pre.fc = E.FC[pool + st.root];
-    // ---- round 3
+    // ---- load stage 3
     const int rk = (pre.inf >> 8) & 0xFF;
     if (do_select) pre.c = load_children(E, pool, g, pre.fc, rk, lane, st.rmode != 0);
 
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(64) void k_tree_step(EngineView E, FinishParams F, 
     if (!do_select) return;
     __syncthreads();  // this wave's tree updates are visible to its own descent
     if (len == 1) {
-        // the leaf was the root itself: its children did not exist when round 3 was issued
+        // the leaf was the root itself: its children did not exist when load stage 3 was issued
         pre.inf = ex.info; pre.fc = ex.first; pre.pn = __shfl(bN, 0);
         const int k = (pre.inf >> 8) & 0xFF;
         pre.c = load_children(E, pool, g, pre.fc, k, lane, st.rmode != 0);

@@ -19,7 +19,10 @@ ap.add_argument("--examples", type=int, default=32768)
 ap.add_argument("--batch", type=int, default=1024)
 ap.add_argument("--blocks", type=int, default=20)
 ap.add_argument("--bf16", action="store_true", help="autocast the forward to bfloat16")
+ap.add_argument("--find", action="store_true", help="let MIOpen time its solvers per layer shape (cudnn.benchmark)")
+ap.add_argument("--channels-last", action="store_true", help="keep weights and activations NHWC")
 a = ap.parse_args()
+torch.backends.cudnn.benchmark = a.find
 rs = np.random.RandomState(0)
 states = (rs.rand(a.examples, 3, 8, 8) > 0.7).astype(np.float32)
 pol = rs.rand(a.examples, 192).astype(np.float32)
@@ -27,6 +30,8 @@ pol /= pol.sum(1, keepdims=True)
 wls = np.tile(np.array([[1.0, 0.0], [0.0, 1.0]], np.float32), (a.examples // 2, 1))
 torch.manual_seed(0)
 model = AlphaZeroNet(num_blocks=a.blocks, num_filters=128).cuda()
+if a.channels_last:
+    model = model.to(memory_format=torch.channels_last)
 tr = ParallelTrainer(model, device="cuda", checkpoint_dir=tempfile.mkdtemp(), verbose=False,
                      autocast_dtype=torch.bfloat16 if a.bf16 else None)
 tr.add_examples(ExampleArrays(states, pol, wls))
