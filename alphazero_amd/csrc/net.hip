@@ -1245,15 +1245,17 @@ template <typename T>
 static int dev_alloc(az_net* n, T*& ptr, size_t count) {
     void* p = nullptr;
     AZ_HIP(hipMalloc(&p, count * sizeof(T)));
+    n->allocs.push_back(p);  // owned from here on: az_net_destroy frees it on every later failure
     AZ_HIP(hipMemset(p, 0, count * sizeof(T)));
     ptr = (T*)p;
-    n->allocs.push_back(p);
     return AZ_OK;
 }
 
 // diagnostic: copies the [workgroups][10] cycle stamps of the last tower launch
 extern "C" int az_net_debug_stamps(az_net* n, unsigned long long* out_host, int32_t workgroups) {
     AZ_CHECK_ARG(n && n->stamps && out_host, "az_net_debug_stamps: stamps are off (set AZ_TOWER_STAMPS=1 before az_net_create)");
+    AZ_CHECK_ARG(workgroups >= 0 && workgroups <= (n->max_batch + 3) / 4,
+                 "az_net_debug_stamps: %d workgroups asked, the network holds stamps for %d", workgroups, (n->max_batch + 3) / 4);
     AZ_HIP(hipDeviceSynchronize());
     AZ_HIP(hipMemcpy(out_host, n->stamps, (size_t)workgroups * 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return AZ_OK;
@@ -1312,10 +1314,12 @@ extern "C" int az_net_create(az_net** out, const az_net_config* cfg) {
     AZ_CHECK_ARG(cfg->num_blocks >= 1 && cfg->num_blocks <= 64, "az_net_create: num_blocks %d out of range", cfg->num_blocks);
     AZ_CHECK_ARG(cfg->max_batch >= 1 && cfg->max_batch <= (1 << 20), "az_net_create: max_batch %d out of range", cfg->max_batch);
     if (cfg->device >= 0) AZ_HIP(hipSetDevice(cfg->device));
+    int device = 0;
+    AZ_HIP(hipGetDevice(&device));
     az_net* n = new az_net();
     n->blocks = cfg->num_blocks;
     n->max_batch = cfg->max_batch;
-    AZ_HIP(hipGetDevice(&n->device));
+    n->device = device;
     const size_t nb = n->blocks, nconv = 2 * nb + 1, B = n->max_batch;
     int rc = AZ_OK;
 #define A(ptr, cnt) if (rc == AZ_OK) rc = dev_alloc(n, n->ptr, (cnt))

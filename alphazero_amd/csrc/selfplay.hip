@@ -243,9 +243,9 @@ static int selfplay_alloc(az_engine* e) {
     do {                                                           \
         void* _p = nullptr;                                        \
         AZ_HIP(hipMalloc(&_p, (count) * sizeof(*(ptr))));          \
+        e->allocs.push_back(_p);                                   \
         AZ_HIP(hipMemset(_p, 0, (count) * sizeof(*(ptr))));        \
         (ptr) = (decltype(ptr))_p;                                 \
-        e->allocs.push_back(_p);                                   \
     } while (0)
     AZ_ALLOC(S.pi, B * 192); AZ_ALLOC(S.chosen, B);
     AZ_ALLOC(S.hist_mine, B * MAX_PLIES); AZ_ALLOC(S.hist_theirs, B * MAX_PLIES);
@@ -264,8 +264,9 @@ extern "C" int az_engine_attach_net(az_engine* e, az_net* n) {
     AZ_CHECK_ARG(e && n, "az_engine_attach_net: null argument");
     AZ_CHECK_ARG(az_net_max_batch(n) >= e->v.B, "az_engine_attach_net: network max_batch %d < n_games %d",
                  az_net_max_batch(n), e->v.B);
-    e->net = n;
-    return selfplay_alloc(e);
+    const int rc = selfplay_alloc(e);
+    if (rc == AZ_OK) e->net = n;  // a network counts as attached only with the self-play buffers in place
+    return rc;
 }
 
 static int check_sticky(az_engine* e, hipStream_t s) {

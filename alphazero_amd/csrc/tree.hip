@@ -314,9 +314,9 @@ static int engine_alloc(az_engine* e) {
     do {                                                                              \
         void* _p = nullptr;                                                           \
         AZ_HIP(hipMalloc(&_p, (count) * sizeof(*(ptr))));                             \
+        e->allocs.push_back(_p);                                                      \
         AZ_HIP(hipMemset(_p, 0, (count) * sizeof(*(ptr))));                           \
         (ptr) = (decltype(ptr))_p;                                                    \
-        e->allocs.push_back(_p);                                                      \
     } while (0)
     AZ_ALLOC(V.white, B); AZ_ALLOC(V.black, B); AZ_ALLOC(V.turn, B); AZ_ALLOC(V.winner, B);
     AZ_ALLOC(V.active, B); AZ_ALLOC(V.ply, B); AZ_ALLOC(V.root, B); AZ_ALLOC(V.used, B);
@@ -353,8 +353,13 @@ extern "C" int az_engine_create(az_engine** out, const az_engine_config* cfg) {
     AZ_CHECK_ARG(cfg->n_games > 0 && cfg->n_games <= (1 << 20), "az_engine_create: n_games = %d out of range",
                  cfg->n_games);
     if (cfg->device >= 0) AZ_HIP(hipSetDevice(cfg->device));
+    int device = 0;
+    AZ_HIP(hipGetDevice(&device));
+    int64_t cap = cfg->pool_nodes_per_game;
+    if (cap <= 0) cap = 1 << 18;
+    AZ_CHECK_ARG(cap >= 64 && cap < (1ll << 31), "az_engine_create: pool_nodes_per_game out of range");
     az_engine* e = new az_engine();
-    AZ_HIP(hipGetDevice(&e->device));
+    e->device = device;
     EngineView& V = e->v;
     V.B = cfg->n_games;
     V.c_puct = cfg->c_puct;
@@ -362,9 +367,6 @@ extern "C" int az_engine_create(az_engine** out, const az_engine_config* cfg) {
     V.eps = cfg->dirichlet_epsilon;
     V.temp_thr = cfg->temperature_threshold;
     V.seed = cfg->seed;
-    int64_t cap = cfg->pool_nodes_per_game;
-    if (cap <= 0) cap = 1 << 18;
-    AZ_CHECK_ARG(cap >= 64 && cap < (1ll << 31), "az_engine_create: pool_nodes_per_game out of range");
     V.cap = (uint32_t)cap;
     const int rc = engine_alloc(e);
     if (rc != AZ_OK) { az_engine_destroy(e); return rc; }
@@ -560,11 +562,12 @@ extern "C" int az_engine_roots_children(az_engine* e, int32_t n, const int32_t* 
         AZ_CHECK_ARG(slots_host[i] >= 0 && slots_host[i] < e->v.B, "az_engine_roots_children: game %d out of range", slots_host[i]);
     hipStream_t s = (hipStream_t)stream;
     if (!e->query_batch_dev) {   // B records, allocated on first use
+        if (!e->query_batch_host)
+            AZ_HIP(hipHostMalloc((void**)&e->query_batch_host, (size_t)e->v.B * sizeof(NodeQuery), hipHostMallocDefault));
         void* p = nullptr;
         AZ_HIP(hipMalloc(&p, (size_t)e->v.B * sizeof(NodeQuery)));
         e->allocs.push_back(p);
-        e->query_batch_dev = (NodeQuery*)p;
-        AZ_HIP(hipHostMalloc((void**)&e->query_batch_host, (size_t)e->v.B * sizeof(NodeQuery), hipHostMallocDefault));
+        e->query_batch_dev = (NodeQuery*)p;   // set last: both buffers exist whenever this one does
     }
     AZ_HIP(hipMemcpyAsync(e->stage_slots, slots_host, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_roots_children, dim3(n), dim3(64), 0, s, e->v, e->stage_slots, e->query_batch_dev);
