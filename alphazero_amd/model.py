@@ -169,19 +169,24 @@ class HipInference:
     def forward_bits(self, mine, theirs, want_logits=False):
         """mine/theirs: int64 cuda tensors holding the canonical bitboards."""
         B = mine.numel()
-        assert mine.is_cuda and theirs.is_cuda and mine.dtype == torch.int64 and theirs.dtype == torch.int64
+        assert mine.dtype == torch.int64 and theirs.dtype == torch.int64 and theirs.numel() == B
+        assert mine.device == self.device and theirs.device == self.device, "inputs live on another device"
+        assert mine.is_contiguous() and theirs.is_contiguous()
         probs, value, pl, wl = self._out(B, want_logits)
-        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        _lib.check(_lib.lib().az_net_forward(self.h, B, self._p(mine), self._p(theirs), self._p(probs),
-                                             self._p(value), self._p(pl), self._p(wl), stream))
+        with torch.cuda.device(self.device):
+            stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            _lib.check(_lib.lib().az_net_forward(self.h, B, self._p(mine), self._p(theirs), self._p(probs),
+                                                 self._p(value), self._p(pl), self._p(wl), stream))
         return probs, value, pl, wl
 
     def forward_planes(self, planes, want_logits=False):
         """planes: [B,3,8,8] float32 cuda tensor of encoded states."""
-        assert planes.is_cuda and planes.dtype == torch.float32 and planes.is_contiguous()
+        assert planes.dtype == torch.float32 and planes.is_contiguous() and tuple(planes.shape[1:]) == (3, 8, 8)
+        assert planes.device == self.device, "input lives on another device"
         B = planes.shape[0]
         probs, value, pl, wl = self._out(B, want_logits)
-        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        _lib.check(_lib.lib().az_net_forward_planes(self.h, B, self._p(planes), self._p(probs),
-                                                    self._p(value), self._p(pl), self._p(wl), stream))
+        with torch.cuda.device(self.device):
+            stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            _lib.check(_lib.lib().az_net_forward_planes(self.h, B, self._p(planes), self._p(probs),
+                                                        self._p(value), self._p(pl), self._p(wl), stream))
         return probs, value, pl, wl
