@@ -9,3 +9,9 @@ pytestmark = pytest.mark.gpu
 def test_random_scenarios_match_the_oracle(seed):
     from fuzz_tree_parity import one_round
     assert one_round(seed, n_games=12, max_plies=6, max_sims=80) > 0
+
+
+@pytest.mark.parametrize("seed", [21, 22, 23, 24, 25, 26])
+def test_random_fused_searches_match_the_step_api(seed):
+    from fuzz_fused_parity import one_round
+    assert one_round(seed, sizes=(3, 37, 130, 300, 520), max_sims=24, max_plies=2) >= 0
