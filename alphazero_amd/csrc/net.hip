@@ -697,23 +697,12 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_tower_split(TowerParams p) {
     if (tid < 512 / 4) reinterpret_cast<uint32_t*>(lds + LDS_ZERO)[tid] = 0;
 
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_void*)lds;
-    // Weight taps: NT = 1 keeps three tap buffers (the third in an activation region it does
-    // not need), each wave owning a private quarter of each; NT = 2 copies one tap ahead into
-    // two shared buffers.
-    constexpr int NBUF = (NT == 1) ? 3 : 2, AHEAD = NBUF - 1;
-    auto tap_buffer = [&](int slot) -> uint32_t {  // slot = tap index modulo NBUF
-        return slot < 2 ? (uint32_t)(LDS_W + slot * TAP_BYTES) : (uint32_t)ACT_REGION;
-    };
+    // Weight taps of the forms with two channel tiles per wave: copied one tap ahead into two
+    // buffers shared by the workgroup.  (NT = 1 keeps its weights in registers, see below.)
+    constexpr int AHEAD = 1;
+    auto tap_buffer = [&](int slot) -> uint32_t { return (uint32_t)(LDS_W + slot * TAP_BYTES); };  // slot = tap parity
     auto prefetch = [&](int T, int slot) {
-        if (NT == 1) {
-            // a wave copies exactly the fragments it reads itself (channel tile nt0 of every
-            // k-step, 1 KB each, 4 KB apart in the tap) into its own 8 KB of the buffer: the weight
-            // stream then needs no workgroup barrier at all
-            const uint8_t* src = p.conv_w + (size_t)T * TAP_BYTES + nt0 * 1024 + lane * 16;
-            const uint32_t dst = lds_base + tap_buffer(slot) + wave_u * 8192;
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) glds16(src + ks * 4096, __builtin_amdgcn_readfirstlane(dst + ks * 1024));
-        } else if (WAVES == 4) {
+        if (WAVES == 4) {
             const uint8_t* src = p.conv_w + (size_t)T * TAP_BYTES + wave_u * 8192 + lane * 16;
             const uint32_t dst = lds_base + tap_buffer(slot) + wave_u * 8192;
             glds16x8(src + 4096, __builtin_amdgcn_readfirstlane(dst + 4096));
@@ -734,8 +723,10 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_tower_split(TowerParams p) {
             glds16(p.se_img + (size_t)blk * SE_BYTES + piece * 1024 + lane * 16,
                    __builtin_amdgcn_readfirstlane(lds_base + LDS_SE + piece * 1024));
     };
+    if constexpr (NT != 1) {
 #pragma unroll
-    for (int t = 0; t < ((NT == 1) ? NBUF : AHEAD); ++t) prefetch(t, t);
+        for (int t = 0; t < AHEAD; ++t) prefetch(t, t);
+    }
     prefetch_bias(0);
 
     uint32_t aaddr[9][2];
@@ -796,11 +787,18 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_tower_split(TowerParams p) {
     wait_weights();
     __syncthreads();  // the first taps landed, zero row and every channel group's stem output visible
 
-    // NT = 1: weight fragments run one tap ahead of the MFMAs, like the activation fragments
-    bf16x8 wc1[8];
+    // NT = 1: a wave is the only reader of its weight fragments (channel tile nt0 of every k-step),
+    // so they never pass through the LDS: three taps of them live in registers, loaded from L2 in
+    // the fragment layout, each 1 KB piece replaced by the same piece three taps on right behind
+    // the MFMAs that read it.  The LDS then carries the activation fragments only.
+    bf16x8 wq[3][8];
+    const uint8_t* wsrc = p.conv_w + nt0 * 1024 + lane * 16;
     if constexpr (NT == 1) {
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) wc1[ks] = lds_read_frag(lds, tap_buffer(0) + wave_u * 8192 + lane * 16 + ks * 1024);
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+                wq[t][ks] = *reinterpret_cast<const bf16x8*>(wsrc + (size_t)t * TAP_BYTES + ks * 4096);
     }
 
     for (int conv = 0; conv < nconv; ++conv) {
@@ -830,61 +828,44 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_tower_split(TowerParams p) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int T = conv * 9 + tap;
-            // T modulo NBUF: 9 is a multiple of 3, and conv * 9 + tap has the parity of conv + tap
-            const int slot = (NBUF == 3) ? tap % 3 : ((conv + tap) & 1);
+            const int slot = (conv + tap) & 1;  // conv * 9 + tap has the parity of conv + tap
             if constexpr (NT == 1) {
-                // Registers hold the fragments of tap T.  One wave per SIMD feeds the matrix pipe, so
-                // everything else is issued between MFMAs.  Per k-step: the two MFMAs; the copy of
-                // the same 1 KB piece of tap T + 3 into the place the MFMAs just read (past the end of
-                // the network the last tap is copied again, into a buffer nobody reads any more, so
-                // that every tap issues the same 8 copies and the counted waits below hold
-                // everywhere); fragment reads of tap T + 1: activations under k-steps 0-3, weights
-                // under k-steps 4-7.  Tap T + 1 has landed when at most the copies issued after it are
-                // in flight: the 8 of tap T + 2 and the 4 of tap T + 3 issued so far (bias / SE pieces
-                // in between only make the wait stricter).
-                bf16x8 wn1[8], xn1[8][2];
-                const uint32_t wb1 = tap_buffer((tap + 1) % 3) + wave_u * 8192 + lane * 16;
+                // One wave per SIMD feeds the matrix pipe, so everything else is issued between MFMAs.
+                // Per k-step: the two MFMAs; the load of the same weight piece of tap T + 3 into the
+                // registers the MFMAs just read (past the end of the network the last tap is loaded
+                // again and never used, so that every tap issues the same 8 loads and the counted wait
+                // at the end of the conv holds everywhere); the activation fragments of k-step ks of
+                // tap T + 1.
+                bf16x8 xn1[8][2];
                 const int T3 = (T + 3 < total_taps) ? T + 3 : total_taps - 1;
-                const uint8_t* src3 = p.conv_w + (size_t)T3 * TAP_BYTES + nt0 * 1024 + lane * 16;
-                const uint32_t dst3 = lds_base + tap_buffer(slot) + wave_u * 8192;
+                const uint8_t* src3 = wsrc + (size_t)T3 * TAP_BYTES;
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc1[ks], xc[ks][0], acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc1[ks], xc[ks][1], acc[0][1], 0, 0, 0);
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[tap % 3][ks], xc[ks][0], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[tap % 3][ks], xc[ks][1], acc[0][1], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (ks == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                    glds16(src3 + ks * 4096, __builtin_amdgcn_readfirstlane(dst3 + ks * 1024));
-                    if (ks < 4) {
-                        if (tap + 1 < 9) {
-#pragma unroll
-                            for (int j = 2 * ks; j < 2 * ks + 2; ++j) {
-                                xn1[j][0] = lds_read_frag(lds, aaddr[tap + 1 < 9 ? tap + 1 : 0][0] + j * 32);
-                                xn1[j][1] = lds_read_frag(lds, aaddr[tap + 1 < 9 ? tap + 1 : 0][1] + j * 32);
-                            }
-                        }
-                    } else {
-                        wn1[2 * (ks - 4)] = lds_read_frag(lds, wb1 + (2 * (ks - 4)) * 1024);      // stale past the last tap, unused
-                        wn1[2 * (ks - 4) + 1] = lds_read_frag(lds, wb1 + (2 * (ks - 4) + 1) * 1024);
+                    wq[tap % 3][ks] = *reinterpret_cast<const bf16x8*>(src3 + ks * 4096);
+                    if (tap + 1 < 9) {
+                        xn1[ks][0] = lds_read_frag(lds, aaddr[tap + 1 < 9 ? tap + 1 : 0][0] + ks * 32);
+                        xn1[ks][1] = lds_read_frag(lds, aaddr[tap + 1 < 9 ? tap + 1 : 0][1] + ks * 32);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (tap == 0 && conv + 1 < nconv) prefetch_bias(conv + 1);
                 if ((conv & 1) && tap < 7 && conv < nconv - 1) prefetch_se(conv >> 1, tap * WAVES + wave_u);
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) wc1[ks] = wn1[ks];
                 if (tap + 1 < 9) {
 #pragma unroll
                     for (int ks = 0; ks < 8; ++ks) { xc[ks][0] = xn1[ks][0]; xc[ks][1] = xn1[ks][1]; }
                 } else {
                     // End of the conv: the SE image and the next bias (copied by other waves too) must
                     // have landed, and every wave must be done reading the activations.  Only the 16
-                    // weight copies of taps 7 and 8 are younger than those pieces.
+                    // weight loads of taps 7 and 8 are younger than those pieces.
                     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                     __syncthreads();
                 }
                 continue;
             }
-            if (T + AHEAD < total_taps) prefetch(T + AHEAD, (NBUF == 3) ? (tap + AHEAD) % 3 : (slot ^ 1));
+            if (T + AHEAD < total_taps) prefetch(T + AHEAD, slot ^ 1);
             if (tap == 0 && conv + 1 < nconv) prefetch_bias(conv + 1);
             if ((conv & 1) && tap < 7 && conv < nconv - 1) prefetch_se(conv >> 1, tap * WAVES + wave_u);
             const uint32_t wb = tap_buffer(slot) + lane * 16 + nt0 * 1024;
@@ -920,8 +901,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_tower_split(TowerParams p) {
             for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    w[ks][nt] = (NT == 1) ? lds_read_frag(lds, tap_buffer(slot) + wave_u * 8192 + lane * 16 + ks * 1024)
-                                          : lds_read_frag(lds, wb + (ks * 4 + nt) * 1024);
+                    w[ks][nt] = lds_read_frag(lds, wb + (ks * 4 + nt) * 1024);
             if (tap + 1 < 9) {
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
@@ -936,16 +916,10 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_tower_split(TowerParams p) {
                     acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks][nt], xc[ks][0], acc[nt][0], 0, 0, 0);
                     acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks][nt], xc[ks][1], acc[nt][1], 0, 0, 0);
                 }
-            // The next tap has landed when at most the copies issued after it are in flight: the 8
-            // of the tap after it (AHEAD = 2), provided that tap exists and was requested above;
-            // bias / SE pieces in between only make the wait stricter.  Behind the last tap of a
-            // conv everything is awaited: the SE image and the bias are read next.
-            if (AHEAD == 2 && tap < 8 && T + AHEAD < total_taps) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else wait_weights();
-            // NT = 2: next tap visible, everyone done reading this buffer.  NT = 1 reads only its own
-            // copies and meets the others after the last tap, when everyone is done reading the
-            // activations (and the bias / SE pieces copied by other waves have landed).
-            if (NT != 1 || tap == 8) __syncthreads();
+            // next tap landed and visible, everyone done reading this buffer (and, behind the last
+            // tap, the activations; the SE image and the bias are read next)
+            wait_weights();
+            __syncthreads();
             if (tap + 1 < 9) {
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) { xc[ks][0] = xn[ks][0]; xc[ks][1] = xn[ks][1]; }
