@@ -40,6 +40,12 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((address_space(3))) void lds_void;
 
+// Cycle stamps inside k_tower_split cost 5 % even when switched off at run time, so they are
+// compiled in only on request (AZ_SPLIT_STAMPS=1 bash build.sh); k_tower always carries its own.
+#ifndef AZ_SPLIT_STAMPS
+#define AZ_SPLIT_STAMPS 0
+#endif
+
 namespace az {
 
 constexpr int CH = 128;                        // filters
@@ -801,7 +807,13 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_tower_split(TowerParams p) {
                 wq[t][ks] = *reinterpret_cast<const bf16x8*>(wsrc + (size_t)t * TAP_BYTES + ks * 4096);
     }
 
+    const bool stamps_on = AZ_SPLIT_STAMPS && p.stamps != nullptr;
+    // diagnostic cycle sums (p.stamps): conv start, tap loops, wait at the end of the taps, plain and
+    // squeeze-excitation epilogues
+    unsigned long long t_pre = 0, t_taps = 0, t_bar = 0, t_ep1 = 0, t_ep2 = 0;
+    const unsigned long long rt0 = stamps_on ? __builtin_amdgcn_s_memrealtime() : 0ull;
     for (int conv = 0; conv < nconv; ++conv) {
+        const unsigned long long ts0 = stamps_on ? __builtin_amdgcn_s_memtime() : 0ull;
         {
             const float* b0 = reinterpret_cast<const float*>(lds + LDS_BIAS + (conv & 1) * 512) + h * 4;
 #pragma unroll
@@ -825,6 +837,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_tower_split(TowerParams p) {
                 xc[ks][1] = lds_read_frag(lds, aaddr[0][1] + ks * 32);
             }
         }
+        const unsigned long long ts1 = stamps_on ? __builtin_amdgcn_s_memtime() : 0ull;
+        unsigned long long ts2 = 0;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int T = conv * 9 + tap;
@@ -860,6 +874,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_tower_split(TowerParams p) {
                     // End of the conv: the SE image and the next bias (copied by other waves too) must
                     // have landed, and every wave must be done reading the activations.  Only the 16
                     // weight loads of taps 7 and 8 are younger than those pieces.
+                    if (stamps_on) ts2 = __builtin_amdgcn_s_memtime();
                     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                     __syncthreads();
                 }
@@ -925,6 +940,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_tower_split(TowerParams p) {
                 for (int ks = 0; ks < 8; ++ks) { xc[ks][0] = xn[ks][0]; xc[ks][1] = xn[ks][1]; }
             }
         }
+        const unsigned long long ts3 = stamps_on ? __builtin_amdgcn_s_memtime() : 0ull;
+        if (NT != 1) ts2 = ts3;
         if (conv == nconv - 1) {
             // ---- policy conv: ReLU -> LDS -> p_act
             store_act_n<NT, true, false>(region, acc, resid, r, h, nt0);
@@ -1068,6 +1085,16 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_tower_split(TowerParams p) {
                 }
             }
         }
+        if (stamps_on) {
+            const unsigned long long ts4 = __builtin_amdgcn_s_memtime();
+            t_pre += ts1 - ts0; t_taps += ts2 - ts1; t_bar += ts3 - ts2;
+            if (conv & 1) t_ep2 += ts4 - ts3; else t_ep1 += ts4 - ts3;
+        }
+    }
+    if (stamps_on && tid == 0 && blockIdx.x < (unsigned)((p.B + 3) / 4)) {
+        unsigned long long* o = p.stamps + blockIdx.x * 10;
+        o[0] = t_taps; o[1] = t_ep1; o[2] = t_ep2; o[3] = __builtin_amdgcn_s_memrealtime() - rt0;
+        o[4] = t_pre; o[5] = t_bar; o[6] = 0; o[7] = 0; o[8] = rt0; o[9] = __builtin_amdgcn_s_memrealtime();
     }
     wait_weights();  // no copy into LDS may outlive the workgroup
 }
@@ -1485,11 +1512,11 @@ int az::net_forward_partial(az_net* n, int32_t B, const uint64_t* mine_dev, cons
     const bool stamp = n->timing && (n->launches++ % TIMING_STRIDE == 0) && n->ev_used < TIMING_POOL;
     if (stamp) AZ_HIP(hipEventRecord(n->ev0[n->ev_used], s));
     // form of the tower: whole positions per wave from 513 positions up, channel-split waves
-    // below (az_net_set_tower_form or AZ_TOWER_FORM force one; the cycle stamps exist in k_tower only)
+    // below (az_net_set_tower_form or AZ_TOWER_FORM force one; with stamps on the default is k_tower, whose stamps are always compiled in)
     static const int env_form = getenv("AZ_TOWER_FORM") ? atoi(getenv("AZ_TOWER_FORM")) : 0;
     const int forced = n->tower_form ? n->tower_form : env_form;
     int form = forced ? forced : (B <= 256 ? 1 : (B <= 512 ? 2 : 4));
-    if (n->stamps || dbg) form = 4;
+    if ((n->stamps && !forced) || dbg) form = 4;
     if (form == 1) hipLaunchKernelGGL((k_tower_split<1, 4>), dim3(B), dim3(256), 0, s, tp);
     else if (form == 2) hipLaunchKernelGGL((k_tower_split<2, 4>), dim3((B + 1) / 2), dim3(256), 0, s, tp);
     else if (form == 8) hipLaunchKernelGGL((k_tower_split<2, 8>), dim3((B + 3) / 4), dim3(512), 0, s, tp);
