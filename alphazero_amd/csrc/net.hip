@@ -855,14 +855,18 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_tower_split(TowerParams p) {
                 const uint8_t* src3 = wsrc + (size_t)T3 * TAP_BYTES;
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
+                    // instructions issue in order: what follows an MFMA issues while it runs, what
+                    // follows two MFMAs in a row waits for the first to leave the pipe
                     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[tap % 3][ks], xc[ks][0], acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[tap % 3][ks], xc[ks][1], acc[0][1], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    wq[tap % 3][ks] = *reinterpret_cast<const bf16x8*>(src3 + ks * 4096);
                     if (tap + 1 < 9) {
                         xn1[ks][0] = lds_read_frag(lds, aaddr[tap + 1 < 9 ? tap + 1 : 0][0] + ks * 32);
                         xn1[ks][1] = lds_read_frag(lds, aaddr[tap + 1 < 9 ? tap + 1 : 0][1] + ks * 32);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[tap % 3][ks], xc[ks][1], acc[0][1], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    wq[tap % 3][ks] = *reinterpret_cast<const bf16x8*>(src3 + ks * 4096);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (tap == 0 && conv + 1 < nconv) prefetch_bias(conv + 1);
