@@ -884,10 +884,52 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_tower_split(TowerParams p) {
                 }
                 continue;
             }
+            const uint32_t wb = tap_buffer(slot) + lane * 16 + nt0 * 1024;
+            if constexpr (WAVES == 4 && NT == 2) {
+                // One wave per SIMD: weight fragments run one k-step ahead of the MFMAs, the activation
+                // fragments of tap T + 1 are fetched as this tap goes, and every read is issued right
+                // behind an MFMA (instructions issue in order: what follows an MFMA issues while it
+                // runs).  The first weight fragments are requested before the copy of the next tap is
+                // set up, so that their latency runs under those instructions.
+                bf16x8 fw[2][NT], xn[8][2];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) fw[0][nt] = lds_read_frag(lds, wb + nt * 1024);
+                if (T + AHEAD < total_taps) prefetch(T + AHEAD, slot ^ 1);
+                if (tap == 0 && conv + 1 < nconv) prefetch_bias(conv + 1);
+                if ((conv & 1) && tap < 7 && conv < nconv - 1) prefetch_se(conv >> 1, tap * WAVES + wave_u);
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const int c = ks & 1, n = c ^ 1;
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[c][0], xc[ks][0], acc[0][0], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ks + 1 < 8) fw[n][0] = lds_read_frag(lds, wb + ((ks + 1) * 4 + 0) * 1024);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[c][0], xc[ks][1], acc[0][1], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ks + 1 < 8) fw[n][1] = lds_read_frag(lds, wb + ((ks + 1) * 4 + 1) * 1024);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[c][1], xc[ks][0], acc[1][0], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (tap + 1 < 9) xn[ks][0] = lds_read_frag(lds, aaddr[tap + 1 < 9 ? tap + 1 : 0][0] + ks * 32);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[c][1], xc[ks][1], acc[1][1], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (tap + 1 < 9) xn[ks][1] = lds_read_frag(lds, aaddr[tap + 1 < 9 ? tap + 1 : 0][1] + ks * 32);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // next tap landed and visible, everyone done reading this buffer (and, behind the last
+                // tap, the activations; the SE image and the bias are read next)
+                wait_weights();
+                __syncthreads();
+                if (tap + 1 < 9) {
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) { xc[ks][0] = xn[ks][0]; xc[ks][1] = xn[ks][1]; }
+                }
+                continue;
+            }
             if (T + AHEAD < total_taps) prefetch(T + AHEAD, slot ^ 1);
             if (tap == 0 && conv + 1 < nconv) prefetch_bias(conv + 1);
             if ((conv & 1) && tap < 7 && conv < nconv - 1) prefetch_se(conv >> 1, tap * WAVES + wave_u);
-            const uint32_t wb = tap_buffer(slot) + lane * 16 + nt0 * 1024;
             if constexpr (WAVES == 8) {
                 // 256 registers per wave: fragments one k-step ahead only; the other wave of the
                 // SIMD covers what this leaves exposed
@@ -914,34 +956,6 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_tower_split(TowerParams p) {
                 wait_weights();
                 __syncthreads();
                 continue;
-            }
-            bf16x8 w[8][NT], xn[8][2];
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    w[ks][nt] = lds_read_frag(lds, wb + (ks * 4 + nt) * 1024);
-            if (tap + 1 < 9) {
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
-                    xn[ks][0] = lds_read_frag(lds, aaddr[tap + 1 < 9 ? tap + 1 : 0][0] + ks * 32);
-                    xn[ks][1] = lds_read_frag(lds, aaddr[tap + 1 < 9 ? tap + 1 : 0][1] + ks * 32);
-                }
-            }
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks][nt], xc[ks][0], acc[nt][0], 0, 0, 0);
-                    acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks][nt], xc[ks][1], acc[nt][1], 0, 0, 0);
-                }
-            // next tap landed and visible, everyone done reading this buffer (and, behind the last
-            // tap, the activations; the SE image and the bias are read next)
-            wait_weights();
-            __syncthreads();
-            if (tap + 1 < 9) {
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) { xc[ks][0] = xn[ks][0]; xc[ks][1] = xn[ks][1]; }
             }
         }
         const unsigned long long ts3 = stamps_on ? __builtin_amdgcn_s_memtime() : 0ull;
