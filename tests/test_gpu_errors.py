@@ -59,6 +59,17 @@ def test_argument_ranges_are_checked():
                              None, None, None, _stream())
     assert rc == -1
     assert L.az_movegen_encode(0, None, None, None, None, None, None, None, _stream()) == 0   # empty input is fine
+    # diagnostics that are switched off answer with an error, not with a read of nothing
+    L.az_net_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    buf = np.zeros((4, 10), np.uint64)
+    assert L.az_net_debug_stamps(inf.h, buf.ctypes.data_as(C.c_void_p), 4) == -1 and b"stamps are off" in L.az_last_error()
+    with pytest.raises(AzError, match="not one of"):
+        inf.set_tower_form(3)
+    # inputs on the host or of the wrong shape never reach the kernels
+    with pytest.raises(AssertionError):
+        inf.forward_planes(torch.ones((2, 3, 8, 8)))
+    with pytest.raises(AssertionError):
+        inf.forward_planes(torch.ones((2, 3, 8, 7), device="cuda"))
 
 
 def test_capacity_errors_are_reported_not_silent():
