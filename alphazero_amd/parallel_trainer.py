@@ -198,17 +198,21 @@ class ParallelTrainer:
         return (isinstance(m, AlphaZeroNet) and m.hip_supported() and str(self.device).startswith("cuda")
                 and type(self.mcts) is MCTS and self.mcts.model is m)
 
-    def execute_parallel_episodes(self, num_games: Optional[int] = None) -> ExampleArrays:
+    def execute_parallel_episodes(self, num_games: Optional[int] = None, continuous: bool = False) -> ExampleArrays:
         """num_games games from the start position to the end, tree reuse, root noise,
         temperature 1 for the first TEMPERATURE_THRESHOLD plies then 0
-        (src/parallel_trainer.py:137-223).  Returns the (state, policy, wl) examples."""
+        (src/parallel_trainer.py:137-223).  Returns the (state, policy, wl) examples.
+        continuous=True (extra; fused path only) keeps num_parallel_games games running all
+        the time and returns once num_games of them have finished (SelfPlay.collect_games):
+        games in progress carry over to the next call."""
         if num_games is None:
             num_games = self.num_parallel_games
         if self._fused_ok():
             from .selfplay import SelfPlay
             sp = self._selfplay
-            if sp is None or sp.engine.n < num_games or sp.num_simulations != self.mcts.num_simulations:
-                sp = self._selfplay = SelfPlay(self.model, n_games=num_games,
+            slots = max(num_games, self.num_parallel_games) if continuous else num_games
+            if sp is None or sp.engine.n < slots or sp.num_simulations != self.mcts.num_simulations:
+                sp = self._selfplay = SelfPlay(self.model, n_games=slots,
                                                num_simulations=self.mcts.num_simulations,
                                                c_puct=self.mcts.c_puct, seed=self.seed,
                                                device=torch.device(self.device).index)
@@ -216,7 +220,11 @@ class ParallelTrainer:
             if self._weights_changed:
                 sp.inference.refresh()
                 self._weights_changed = False
+            if continuous:
+                return ExampleArrays(*sp.collect_games(num_games))
             return ExampleArrays(*sp.execute_parallel_episodes(num_games))
+        if continuous:
+            raise RuntimeError("continuous self-play runs on the fused engine only (a HIP-supported AlphaZeroNet on a GPU)")
         return self._host_loop_episodes(num_games)
 
     def _host_loop_episodes(self, num_games: int) -> ExampleArrays:

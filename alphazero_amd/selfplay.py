@@ -32,12 +32,38 @@ class SelfPlay:
         n = e.n if num_games is None else int(num_games)
         assert n <= e.n
         e.reset_all()
+        self._continuous = False
         active = np.zeros(e.n, np.uint8)
         active[:n] = 1
         e.set_active(active)
         out = [[], [], []]
         while e.stats()["games_finished"] - getattr(self, "_finished0", 0) < n:
             e.play_move(self.num_simulations, add_noise=True, restart_finished=False)
+            if e.samples_pending() > e.n * 64:
+                for o, t in zip(out, e.drain_samples()):
+                    o.append(t.cpu())
+        for o, t in zip(out, e.drain_samples()):
+            o.append(t.cpu())
+        self._finished0 = e.stats()["games_finished"]
+        return tuple(torch.cat(o).numpy() for o in out)
+
+    def collect_games(self, num_games=None):
+        """Continuous self-play: every slot of the engine stays busy (a finished game restarts
+        from the start position at once) until num_games more games have finished; returns
+        their examples like execute_parallel_episodes.  Games still running when the call
+        returns stay in the engine and go on in the next call, so no launch ever runs below
+        the engine's full batch - the reference's loop, whose batch shrinks as games finish,
+        has no counterpart for this; it is the faster way to fill a replay buffer."""
+        e = self.engine
+        n = e.n if num_games is None else int(num_games)
+        if not getattr(self, "_continuous", False):
+            e.reset_all()
+            e.set_active(np.ones(e.n, np.uint8))
+            self._continuous = True
+        start = e.stats()["games_finished"]
+        out = [[], [], []]
+        while e.stats()["games_finished"] - start < n:
+            e.play_move(self.num_simulations, add_noise=True, restart_finished=True)
             if e.samples_pending() > e.n * 64:
                 for o, t in zip(out, e.drain_samples()):
                     o.append(t.cpu())

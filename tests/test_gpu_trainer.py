@@ -80,3 +80,31 @@ def test_fused_selfplay_train_refresh_cycle(tmp_path):
     tr.save_iteration_checkpoint(1)
     assert tr.get_latest_iteration() == 1
     assert tr.load_training_data() == len(ex)
+
+
+def test_continuous_collection_keeps_every_slot_busy(tmp_path):
+    """continuous=True: the engine's slots all stay active, a call returns once the asked
+    number of games has finished, games in progress carry over to the next call, and the
+    examples have the same form as the episodic ones."""
+    from alphazero_amd.model import AlphaZeroNet
+    from alphazero_amd.parallel_trainer import ParallelTrainer
+    torch.manual_seed(1)
+    tr = ParallelTrainer(AlphaZeroNet(num_blocks=1, num_filters=128).cuda(), device="cuda", num_parallel_games=16,
+                         num_simulations=8, checkpoint_dir=str(tmp_path), seed=5, verbose=False)
+    first = tr.execute_parallel_episodes(6, continuous=True)
+    eng = tr._selfplay.engine
+    assert eng.n == 16
+    done1, moves1 = eng.stats()["games_finished"], eng.stats()["moves"]
+    assert done1 >= 6 and len(first) >= 6 * 10
+    second = tr.execute_parallel_episodes(6, continuous=True)
+    st = eng.stats()
+    assert st["games_finished"] - done1 >= 6 and st["moves"] > moves1
+    for ex in (first, second):
+        assert np.allclose(ex.policies.sum(1), 1.0, atol=1e-5)
+        assert np.all(ex.wls.sum(1) == 1.0) and np.all(ex.states[:, 2] == 1.0)
+    # the second call did not start from scratch: its first finished games needed fewer plies inside
+    # the call than a whole game takes, so it finished its six games in fewer moves than the first
+    assert st["moves"] - moves1 < moves1
+    # the episodic mode afterwards starts clean
+    third = tr.execute_parallel_episodes(4)
+    assert len(third) >= 4 * 10
