@@ -341,6 +341,73 @@ def make_tree_cpuct_tier():
     print("c_puct tier done")
 
 
+# ------------------------------------------------------------------ deep reuse tier
+def make_tree_deep_tier():
+    """Four games played for up to 30 plies at 800 simulations per move with root noise and tree
+    reuse: trees of several thousand nodes, long backup chains, reused roots with float64
+    noise mixed into float32 priors again and again."""
+    roots_pos = tree_positions()
+    games = [roots_pos[i].clone() for i in (0, 3, 5, 7)]
+    nG, S, plies = len(games), 800, 30
+    m = TableMCTS(None, num_simulations=S, c_puct=1.5)
+    roots = [None] * nG
+    rs = np.random.RandomState(123)
+    actions = np.full((plies, nG), 255, np.int16)
+    noise_rec = np.zeros((plies, nG, 48), np.float64)
+    stats = []
+    alive = [True] * nG
+    np.random.seed(77)
+    orig = np.random.dirichlet
+    for ply in range(plies):
+        idx = [i for i in range(nG) if alive[i]]
+        if not idx:
+            stats.append([None] * nG)
+            continue
+        drawn = []
+
+        def rec(alpha, *a, **k):
+            v = orig(alpha, *a, **k)
+            drawn.append(v)
+            return v
+        np.random.dirichlet = rec
+        try:
+            new_roots = m.search_batch([games[i] for i in idx], [roots[i] for i in idx], add_noise=True)
+        finally:
+            np.random.dirichlet = orig
+        for j, i in enumerate(idx):
+            roots[i] = new_roots[j]
+            noise_rec[ply, i, :len(drawn[j])] = drawn[j]
+        ply_stats = []
+        for i in range(nG):
+            if not alive[i]:
+                ply_stats.append(None)
+                continue
+            ply_stats.append(root_stats(roots[i]))
+            probs = m.get_action_probs(roots[i], temperature=1.0 if ply < 8 else 0.0)
+            a = int(rs.choice(192, p=probs.astype(np.float64) / probs.astype(np.float64).sum()))
+            actions[ply, i] = a
+            games[i].step(games[i].decode_action(a))
+            roots[i] = roots[i].children[a] if a in roots[i].children else None
+            if games[i].is_terminal():
+                alive[i] = False
+        stats.append(ply_stats)
+    out = {}
+    wb = [game_bits(roots_pos[i]) for i in (0, 3, 5, 7)]
+    out["white"] = np.array([x[0] for x in wb], np.uint64)
+    out["black"] = np.array([x[1] for x in wb], np.uint64)
+    out["turn"] = np.array([roots_pos[i].turn for i in (0, 3, 5, 7)], np.int8)
+    out["sims"] = np.array(S)
+    out["played"] = actions
+    out["noise"] = noise_rec
+    empty = dict(k=0, root_N=0, actions=np.full(48, 255, np.uint8), N=np.zeros(48, np.uint32),
+                 W=np.zeros(48, np.float32), P=np.zeros(48, np.float64), p_is64=np.zeros(48, np.uint8))
+    for key in empty:
+        out[key] = np.array([[(s or empty)[key] for s in ps] for ps in stats])
+    np.savez_compressed(os.path.join(HERE, "tree_deep_tier.npz"), **out)
+    print("deep tier: plies played per game", [(actions[:, i] != 255).sum() for i in range(nG)],
+          "max root N", int(out["root_N"].max()))
+
+
 # ------------------------------------------------------------------ self-play tier
 def make_selfplay_tier(nG=3, S=30, seed=31337, name="selfplay_tier.npz"):
     tmp = tempfile.mkdtemp()
@@ -487,7 +554,7 @@ def make_train_tier():
 if __name__ == "__main__":
     torch.set_num_threads(4)
     tiers = {"table": make_table, "game": make_game_tier, "tree": make_tree_tier,
-             "tree_wide": make_tree_wide_tier, "tree_cpuct": make_tree_cpuct_tier,
+             "tree_wide": make_tree_wide_tier, "tree_cpuct": make_tree_cpuct_tier, "tree_deep": make_tree_deep_tier,
              "selfplay": make_selfplay_tier, "selfplay_wide": make_selfplay_wide_tier, "nn": make_nn_tier, "train": make_train_tier}
     for name in (sys.argv[1:] or list(tiers)):
         tiers[name]()

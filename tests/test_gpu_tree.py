@@ -179,3 +179,13 @@ def test_other_exploration_constants_match_reference(golden_dir, tag):
     m.search(TableEvaluator(), int(d[f"{tag}_sims"]), noise=noise)
     for g in range(nG):
         _check_children(m.root_children(g), d, tag, g)
+
+
+def test_deep_reuse_matches_reference(golden_dir):
+    """800 simulations per move, recorded root noise, tree reuse over up to 30 plies
+    (tree_deep_tier.npz) on the device engine."""
+    from gpu_backend import EngineBackend
+    from test_oracle_golden import replay_deep_tier
+    d = np.load(os.path.join(golden_dir, "tree_deep_tier.npz"))
+    checked, top = replay_deep_tier(EngineBackend(len(d["white"]), pool_nodes_per_game=1 << 16), d)
+    assert checked == int((d["played"] != 255).sum()) and top > 1500

@@ -172,3 +172,44 @@ def test_tree_other_exploration_constants_bit_exact(golden_dir, tag):
     m.search(TableEvaluator(), int(d[f"{tag}_sims"]), noise=noise)
     for g in range(nG):
         _check_children(m.root_children(g), d, tag, g)
+
+
+def replay_deep_tier(m, d):
+    """Drives a backend (oracle or device adapter) through tree_deep_tier.npz: 800 simulations per
+    move with the recorded root noise, tree reuse over up to 30 plies; every root must equal the
+    reference's.  Returns the number of roots compared and the largest root visit count seen."""
+    nG = len(d["white"])
+    for g in range(nG):
+        m.set_game(g, orc.make_pos(d["white"][g], d["black"][g], d["turn"][g]))
+    ev = TableEvaluator()
+    S = int(d["sims"])
+    alive = np.ones(nG, bool)
+    checked = top = 0
+    for ply in range(d["played"].shape[0]):
+        if not alive.any():
+            break
+        m.set_active(alive.astype(np.uint8))
+        m.search(ev, S, noise=d["noise"][ply])
+        for g in range(nG):
+            if not alive[g]:
+                continue
+            st = m.root_children(g)
+            k = int(d["k"][ply, g])
+            assert st is not None and len(st["actions"]) == k and st["root_N"] == int(d["root_N"][ply, g]), (ply, g)
+            assert np.array_equal(st["actions"], d["actions"][ply, g][:k])
+            assert np.array_equal(st["N"], d["N"][ply, g][:k]), (ply, g)
+            assert np.array_equal(st["W"].view(np.uint32), d["W"][ply, g][:k].view(np.uint32)), (ply, g)
+            assert np.array_equal(st["p_is64"], d["p_is64"][ply, g][:k])
+            assert np.array_equal(st["P"].view(np.uint64), d["P"][ply, g][:k].view(np.uint64)), (ply, g)
+            checked += 1
+            top = max(top, st["root_N"])
+            m.advance(g, int(d["played"][ply, g]))
+            if orc.is_terminal(m.get_game(g)):
+                alive[g] = False
+    return checked, top
+
+
+def test_tree_deep_reuse_bit_exact(golden_dir):
+    d = np.load(os.path.join(golden_dir, "tree_deep_tier.npz"))
+    checked, top = replay_deep_tier(orc.OracleMCTS(len(d["white"]), c_puct=1.5), d)
+    assert checked == int((d["played"] != 255).sum()) and top > 1500
