@@ -408,6 +408,36 @@ def make_tree_deep_tier():
           "max root N", int(out["root_N"].max()))
 
 
+# ------------------------------------------------------------------ action-probability tier
+def make_probs_tier():
+    """get_action_probs of the reference on hand-built roots: random visit counts (ties, one
+    root without any visit, one without children) at temperatures 0, 0.25, 0.5, 1 and 2."""
+    rs = np.random.RandomState(8)
+    temps = [0.0, 0.25, 0.5, 1.0, 2.0]
+    m = MCTS(None, num_simulations=1)
+    acts, visits, out = [], [], []
+    for case in range(14):
+        k = 0 if case == 13 else int(rs.randint(1, 40))
+        a = np.sort(rs.choice(168, size=k, replace=False))
+        if case == 12:
+            n = np.zeros(k, np.int64)
+        elif case % 3 == 0:
+            n = rs.randint(0, 4, size=k) * 50           # many ties
+        else:
+            n = rs.randint(0, 800, size=k)
+        root = Node(0)
+        for ai, ni in zip(a, n):
+            c = Node(0.1)
+            c.visit_count = int(ni)
+            root.children[int(ai)] = c
+        acts.append(np.concatenate([a, np.full(48 - k, 255)]).astype(np.uint8))
+        visits.append(np.concatenate([n, np.zeros(48 - k, np.int64)]).astype(np.uint32))
+        out.append(np.stack([m.get_action_probs(root, temperature=t) for t in temps]))
+    np.savez_compressed(os.path.join(HERE, "probs_tier.npz"), temps=np.array(temps), actions=np.array(acts),
+                        visits=np.array(visits), probs=np.array(out, np.float32))
+    print("probs tier:", len(out), "roots x", len(temps), "temperatures")
+
+
 # ------------------------------------------------------------------ self-play tier
 def make_selfplay_tier(nG=3, S=30, seed=31337, name="selfplay_tier.npz"):
     tmp = tempfile.mkdtemp()
@@ -554,7 +584,7 @@ def make_train_tier():
 if __name__ == "__main__":
     torch.set_num_threads(4)
     tiers = {"table": make_table, "game": make_game_tier, "tree": make_tree_tier,
-             "tree_wide": make_tree_wide_tier, "tree_cpuct": make_tree_cpuct_tier, "tree_deep": make_tree_deep_tier,
+             "tree_wide": make_tree_wide_tier, "tree_cpuct": make_tree_cpuct_tier, "tree_deep": make_tree_deep_tier, "probs": make_probs_tier,
              "selfplay": make_selfplay_tier, "selfplay_wide": make_selfplay_wide_tier, "nn": make_nn_tier, "train": make_train_tier}
     for name in (sys.argv[1:] or list(tiers)):
         tiers[name]()
