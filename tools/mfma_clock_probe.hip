@@ -45,7 +45,8 @@ __global__ __launch_bounds__(256, 1) void k16(const bf16x8* src, float* out, int
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
-int main() {
+int main(int argc, char** argv) {
+    const int reps = argc > 1 ? atoi(argv[1]) : 3;  // many repetitions give a power probe time to sample
     const int n = 256 * 12 * 8;
     std::vector<unsigned short> h(n);
     srand(1);
@@ -55,7 +56,7 @@ int main() {
     hipMemcpy(src, h.data(), n * 2, hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int shape = 0; shape < 2; ++shape) {
-        for (int rep = 0; rep < 3; ++rep) {
+        for (int rep = 0; rep < reps; ++rep) {
             const int iters = shape == 0 ? 60000 : 15000;  // same FLOPs: 8 x 32768 vs 32 x 16384 per iteration
             hipEventRecord(e0);
             if (shape == 0) hipLaunchKernelGGL(k32, dim3(256), dim3(256), 0, 0, (const bf16x8*)src, (float*)out, iters);
@@ -63,7 +64,7 @@ int main() {
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             const double flop = (shape == 0 ? 8.0 * 32768 : 32.0 * 16384) * iters * 1024.0;
-            printf("%s: %.2f ms, %.1f TFLOP/s\n", shape == 0 ? "32x32x16" : "16x16x32", ms, flop / ms * 1e-9);
+            if (rep < 3 || rep == reps - 1) printf("%s: %.2f ms, %.1f TFLOP/s\n", shape == 0 ? "32x32x16" : "16x16x32", ms, flop / ms * 1e-9);
         }
     }
     return 0;
