@@ -104,6 +104,9 @@ struct Rng {
 
 enum Phase { PHASE_IDLE = 0, PHASE_ROOTS = 1, PHASE_SELECTED = 2 };
 
+// k_finish_scan's verdict on a game after a move
+constexpr int FIN_NONE = 0, FIN_BLACK = 1, FIN_WHITE = 2, FIN_DROPPED = 4;  // DROPPED: queue full
+
 constexpr int MAX_PLIES = 256;  // per-game history depth (a game lasts < 200 plies)
 
 // Self-play bookkeeping on the device (selfplay.hip): per-game move history and
@@ -119,6 +122,8 @@ struct SelfplayView {
     float* q_wl;            // [Q][2]
     float* q_pi;            // [Q][192]
     uint32_t* q_count;      // samples in the queue
+    uint32_t* fin_base;     // [B] queue position of a game that finished with this move
+    uint8_t* fin_flag;      // [B] FIN_* of this move
     uint32_t q_cap;
     unsigned long long* stat;  // [0] moves, [1] games finished
 };
@@ -153,6 +158,8 @@ struct az_engine {
 };
 
 namespace az {
+// tree.hip: report and clear the device error word; synchronises
+int check_engine_error(az_engine* e, hipStream_t s);
 // tree.hip: sums of the per-game counters {depth, descents, terminal, rootexp}; synchronises
 int engine_counters(az_engine* e, unsigned long long out[4], hipStream_t s);
 // tree.hip: play the actions held in a device array (same as az_engine_advance)

@@ -72,30 +72,77 @@ __global__ __launch_bounds__(64) void k_record_and_choose(EngineView E, Selfplay
     if (lane == 0) S.chosen[g] = (int16_t)action;
 }
 
-// After the move: finished games emit their samples (src/parallel_trainer.py:201-213)
-// and either restart from the initial position or leave the active set (:216-217).
+// After the move: which games have finished, and where their samples go in the queue.
+// The reference walks its active list in game order and appends a finished game's samples
+// as it meets it (src/parallel_trainer.py:176-217), so within a ply samples are queued in
+// ascending game index: queue space is handed out by an exclusive scan over the games,
+// never by the order in which workgroups happen to arrive.  One workgroup of 1024 lanes,
+// 1024 games per pass.  A game whose samples do not fit the queue is marked as such
+// (ERR_HISTORY) and the queue length is left at the first game that did not fit; space is
+// never reserved and given back.
+__global__ __launch_bounds__(1024) void k_finish_scan(EngineView E, SelfplayView S) {
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry, s_limit;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { s_carry = *S.q_count; s_limit = 0xFFFFFFFFu; }
+    __syncthreads();
+    for (int g0 = 0; g0 < E.B; g0 += 1024) {
+        const int g = g0 + tid;
+        uint32_t n = 0;
+        int fin = FIN_NONE;
+        if (g < E.B && E.active[g] && S.chosen[g] >= 0) {
+            const uint64_t w = E.white[g], b = E.black[g];
+            const int t = E.turn[g], win = E.winner[g];
+            bool terminal = (win != 0);
+            int white_won = (win > 0);
+            if (!terminal) {
+                const uint64_t mine = (t > 0) ? w : bitrev64(b), theirs = (t > 0) ? b : bitrev64(w);
+                const Legal3 l = legal_sources(mine, theirs);
+                if ((l.fwd | l.dl | l.dr) == 0) { terminal = true; white_won = (t < 0); }  // side to move loses
+            }
+            if (terminal) { fin = white_won ? FIN_WHITE : FIN_BLACK; n = min((uint32_t)E.ply[g], (uint32_t)MAX_PLIES); }
+        }
+        uint32_t incl = n;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const uint32_t x = s_wave[i]; total += x; if (i < wave) before += x; }
+        const uint32_t base = s_carry + before + incl - n;
+        if (g < E.B) {
+            const bool fits = (uint64_t)base + n <= (uint64_t)S.q_cap;
+            if (fin != FIN_NONE && !fits) { fin |= FIN_DROPPED; atomicMin(&s_limit, base); }
+            S.fin_flag[g] = (uint8_t)fin;
+            S.fin_base[g] = base;
+        }
+        __syncthreads();
+        if (tid == 0) s_carry += total;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (s_limit != 0xFFFFFFFFu) { atomicOr(E.err, ERR_HISTORY); *S.q_count = s_limit; }
+        else *S.q_count = s_carry;
+    }
+}
+
+// Finished games emit their samples (src/parallel_trainer.py:201-213) at the queue position
+// k_finish_scan gave them, and either restart from the initial position or leave the
+// active set (:216-217).
 __global__ __launch_bounds__(64) void k_finish_games(EngineView E, SelfplayView S, int restart) {
-    __shared__ uint32_t s_base;
     const int g = blockIdx.x, lane = threadIdx.x;
     if (!E.active[g] || S.chosen[g] < 0) return;
     if (lane == 0) atomicAdd(&S.stat[0], 1ull);
-    const uint64_t w = E.white[g], b = E.black[g];
-    const int t = E.turn[g], win = E.winner[g];
-    bool terminal = (win != 0);
-    int white_won = (win > 0);
-    if (!terminal) {
-        const uint64_t mine = (t > 0) ? w : bitrev64(b), theirs = (t > 0) ? b : bitrev64(w);
-        const Legal3 l = legal_sources(mine, theirs);
-        if ((l.fwd | l.dl | l.dr) == 0) { terminal = true; white_won = (t < 0); }  // side to move loses
-    }
-    if (!terminal) return;
-    const int n = min((int)E.ply[g], MAX_PLIES);
-    if (lane == 0) s_base = atomicAdd(S.q_count, (uint32_t)n);
-    __syncthreads();
-    const uint32_t base = s_base;
-    if (base + (uint32_t)n > S.q_cap) {
-        if (lane == 0) { atomicOr(E.err, ERR_HISTORY); atomicSub(S.q_count, (uint32_t)n); }
-    } else {
+    const int fin = S.fin_flag[g];
+    if (fin == FIN_NONE) return;
+    if (!(fin & FIN_DROPPED)) {
+        const int n = min((int)E.ply[g], MAX_PLIES);
+        const uint32_t base = S.fin_base[g];
+        const bool white_won = (fin & FIN_WHITE) != 0;
         const float wv = white_won ? 1.f : 0.f, lv = white_won ? 0.f : 1.f;
         for (int i = 0; i < n; ++i) {
             const size_t hrow = (size_t)g * MAX_PLIES + i, q = (size_t)base + i;
@@ -253,6 +300,7 @@ static int selfplay_alloc(az_engine* e) {
     AZ_ALLOC(S.q_mine, (size_t)S.q_cap); AZ_ALLOC(S.q_theirs, (size_t)S.q_cap);
     AZ_ALLOC(S.q_wl, (size_t)S.q_cap * 2); AZ_ALLOC(S.q_pi, (size_t)S.q_cap * 192);
     AZ_ALLOC(S.q_count, 1); AZ_ALLOC(S.stat, 4);
+    AZ_ALLOC(S.fin_base, B); AZ_ALLOC(S.fin_flag, B);
     AZ_ALLOC(e->nn_probs, B * 192); AZ_ALLOC(e->nn_values, B);
     AZ_ALLOC(e->row_of_dev, B); AZ_ALLOC(e->game_of_dev, B);
 #undef AZ_ALLOC
@@ -269,16 +317,7 @@ extern "C" int az_engine_attach_net(az_engine* e, az_net* n) {
     return rc;
 }
 
-static int check_sticky(az_engine* e, hipStream_t s) {
-    int32_t flag = 0;
-    AZ_HIP(hipMemcpyAsync(&flag, e->v.err, sizeof flag, hipMemcpyDeviceToHost, s));
-    AZ_HIP(hipStreamSynchronize(s));
-    if (flag & ERR_POOL) AZ_FAIL(AZ_ERR_CAPACITY, "node pool exhausted (pool_nodes_per_game = %u)", e->v.cap);
-    if (flag & ERR_DEPTH) AZ_FAIL(AZ_ERR_CAPACITY, "selection path deeper than %d", MAX_DEPTH);
-    if (flag & ERR_NODE) AZ_FAIL(AZ_ERR_ARG, "az_engine_set_roots: a game slot or node index was out of range");
-    if (flag & ERR_HISTORY) AZ_FAIL(AZ_ERR_CAPACITY, "sample queue or per-game history exhausted: drain samples more often");
-    return AZ_OK;
-}
+static int check_sticky(az_engine* e, hipStream_t s) { return az::check_engine_error(e, s); }
 
 // MCTS.search_batch (src/mcts.py:94-189) with the attached network.  Per simulation
 // three launches: tower, head GEMMs, k_tree_step.
@@ -349,6 +388,7 @@ extern "C" int az_engine_play_move(az_engine* e, int32_t num_simulations, int32_
     }
     hipLaunchKernelGGL(k_record_and_choose, dim3(e->v.B), dim3(64), 0, s, e->v, e->sp, inj, ++e->move_calls);
     if ((rc = az::advance_dev(e, e->sp.chosen, s))) return rc;
+    hipLaunchKernelGGL(k_finish_scan, dim3(1), dim3(1024), 0, s, e->v, e->sp);
     hipLaunchKernelGGL(k_finish_games, dim3(e->v.B), dim3(64), 0, s, e->v, e->sp, restart_finished);
     AZ_HIP(hipGetLastError());
     return check_sticky(e, s);

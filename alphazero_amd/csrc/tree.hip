@@ -383,15 +383,28 @@ extern "C" int az_engine_destroy(az_engine* e) {
     return AZ_OK;
 }
 
-static int check_err(az_engine* e, hipStream_t s) {
+// Reads the device error word (synchronises).  A condition is reported once: the word is
+// cleared behind the read, so one tree that outgrew its pool, or one bad index, does not
+// fail every later call on an engine whose other games are fine.  What the failed step
+// left behind is consistent: a leaf that could not be expanded stays a leaf, a game whose
+// samples did not fit the queue is dropped whole.
+int az::check_engine_error(az_engine* e, hipStream_t s) {
     int32_t flag = 0;
     AZ_HIP(hipMemcpyAsync(&flag, e->v.err, sizeof flag, hipMemcpyDeviceToHost, s));
+    AZ_HIP(hipStreamSynchronize(s));
+    if (flag == 0) return AZ_OK;
+    AZ_HIP(hipMemsetAsync(e->v.err, 0, sizeof(int32_t), s));
     AZ_HIP(hipStreamSynchronize(s));
     if (flag & ERR_POOL) AZ_FAIL(AZ_ERR_CAPACITY, "node pool exhausted (pool_nodes_per_game = %u)", e->v.cap);
     if (flag & ERR_DEPTH) AZ_FAIL(AZ_ERR_CAPACITY, "selection path deeper than %d", MAX_DEPTH);
     if (flag & ERR_NODE) AZ_FAIL(AZ_ERR_ARG, "az_engine_set_roots: a game slot or node index was out of range");
-    return AZ_OK;
+    if (flag & ERR_HISTORY)
+        AZ_FAIL(AZ_ERR_CAPACITY, "sample queue full or a game longer than %d plies: samples were dropped "
+                                 "(drain the queue before it holds %u samples)", MAX_PLIES, e->sp.q_cap);
+    AZ_FAIL(AZ_ERR_STATE, "unknown device error flag %d", flag);
 }
+
+static int check_err(az_engine* e, hipStream_t s) { return az::check_engine_error(e, s); }
 
 static int set_positions_impl(az_engine* e, int32_t n, const int32_t* slots_host,
                               const uint64_t* white_host, const uint64_t* black_host,

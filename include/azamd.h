@@ -206,7 +206,10 @@ int az_engine_set_root(az_engine* e, int32_t g, int64_t node, void* stream);
  * the game's tree is reported by the next call that checks the engine's error flag. */
 int az_engine_set_roots(az_engine* e, int32_t n, const int32_t* slots_host, const int64_t* nodes_host, void* stream);
 
-/* Diagnostics: nodes in use per game, sticky capacity-error flag. */
+/* Diagnostics: nodes in use per game.  Like every call that synchronises, it reports a
+ * pending device-side error (node pool exhausted, path too deep, bad node index, sample
+ * queue full).  A condition is reported once and then cleared: the engine stays usable,
+ * the game that hit the limit keeps a consistent but incomplete tree. */
 int az_engine_pool_usage(az_engine* e, uint32_t* used_host, void* stream);
 /* Sum of selection path lengths (nodes below the root) and number of descents
  * since creation: mean depth = depth_sum / descents. */

@@ -72,7 +72,7 @@ def test_argument_ranges_are_checked():
         inf.forward_planes(torch.ones((2, 3, 8, 7), device="cuda"))
 
 
-def test_capacity_errors_are_reported_not_silent():
+def test_capacity_errors_are_reported_once_and_the_engine_stays_usable():
     from alphazero_amd._lib import AzError
     from alphazero_amd.engine import Engine
     from alphazero_amd.model import AlphaZeroNet, HipInference
@@ -81,10 +81,59 @@ def test_capacity_errors_are_reported_not_silent():
     e = Engine(8, pool_nodes_per_game=128)            # far too small for 64 simulations
     e.attach_net(inf)
     e.reset_all()
-    e.set_active(np.ones(8, np.uint8))
+    only0 = np.zeros(8, np.uint8)
+    only0[0] = 1
+    e.set_active(only0)
     with pytest.raises(AzError, match="node pool exhausted"):
         e.search(64)
-        e.pool_usage()
-    # the flag is sticky: later calls on the engine keep reporting it
+    # reported once: the flag is cleared behind the report, the other slots of the engine
+    # (the drop-in MCTS keeps up to 64 unrelated trees on one engine) are not affected
+    e.pool_usage()
+    only1 = np.zeros(8, np.uint8)
+    only1[1] = 1
+    e.set_active(only1)
+    e.search(3)                                       # a fresh slot searches fine (22 + 3 x <= 23 nodes fit)
+    q = e.root_children(1)
+    assert q["root_N"] == 3 and int(q["N"].sum()) == 3
+    # the overgrown tree is still a consistent tree: its root has its 22 children and every
+    # simulation was backed up
+    q0 = e.root_children(0)
+    assert len(q0["actions"]) == 22 and q0["root_N"] == 64 and int(q0["N"].sum()) == 64
+    # searching it again hits the limit again and says so again
+    e.set_active(only0)
     with pytest.raises(AzError, match="node pool exhausted"):
-        e.pool_usage()
+        e.search(8)
+    e.pool_usage()
+
+
+def test_full_sample_queue_drops_whole_games_and_keeps_the_count_consistent():
+    """Queue space is handed out in game order by a scan; a game that does not fit is dropped
+    whole, the queue length never counts samples that were not written, and draining the
+    queue makes room again."""
+    from alphazero_amd._lib import AzError
+    from alphazero_amd.model import AlphaZeroNet
+    from alphazero_amd.selfplay import SelfPlay
+    torch.manual_seed(2)
+    nG = 640                                          # queue capacity is max(65536, 160 * n_games) samples
+    sp = SelfPlay(AlphaZeroNet(num_blocks=1, num_filters=128).eval(), n_games=nG, num_simulations=1, seed=4,
+                  pool_nodes_per_game=1 << 10)
+    e = sp.engine
+    overflowed = False
+    for _ in range(400):
+        try:
+            sp.step(restart_finished=True)
+        except AzError as exc:
+            assert "sample queue full" in str(exc)
+            overflowed = True
+            break
+    assert overflowed, "400 plies of 640 restarting games must overflow 102400 queue slots"
+    pending = e.samples_pending()
+    assert pending <= 160 * nG
+    s, p, wl = e.drain_samples()
+    assert len(s) == pending
+    assert np.allclose(p.sum(1).cpu().numpy(), 1.0, atol=1e-5)           # only complete, written rows are counted
+    assert bool((wl.sum(1) == 1.0).all()) and bool((s[:, 2] == 1.0).all())
+    assert e.samples_pending() == 0
+    sp.step(restart_finished=True)                    # room again: no error
+
+

@@ -250,3 +250,57 @@ def test_fused_search_packs_the_active_games(small_model):
     active[:] = 0
     fused.set_active(active)
     fused.search(S)                      # nothing active: a no-op, not an error
+
+
+@pytest.mark.parametrize("fixture", ["selfplay_tier.npz", "selfplay_wide_tier.npz"])
+def test_fused_sample_stream_equals_the_reference_stream(golden_dir, small_model, fixture):
+    """The product kernels of the self-play bookkeeping (record-and-choose, finish scan, sample
+    queue, unpack on drain: az_engine_play_move + az_engine_drain_samples) against the stream the
+    reference's execute_parallel_episodes produced with a table network and recorded numpy draws
+    (tests/golden/make_golden.py selfplay): every (state, pi, wl) example, in the reference's
+    order.  The search of each ply runs through the step API with the table network and the
+    recorded Dirichlet rows; play_move then does everything after the search with the recorded
+    moves injected."""
+    import os
+    from fake_net import TableEvaluator
+    from gpu_backend import HostEvaluatorOnDevice
+    from alphazero_amd.engine import Engine
+    from alphazero_amd.model import HipInference
+    d = np.load(os.path.join(golden_dir, fixture))
+    nG, S = int(d["n_games"]), int(d["sims"])
+    e = Engine(nG, pool_nodes_per_game=1 << 14)
+    # play_move wants a network attached; every root is already expanded when it is called
+    # here, so nothing the network computes is consumed
+    e.attach_net(HipInference(small_model, max_batch=max(16, nG)))
+    e.reset_all()
+    evaluate = HostEvaluatorOnDevice(TableEvaluator(), e.device)
+    pos = [orc.start_position() for _ in range(nG)]
+    active = list(range(nG))
+    di = ci = 0
+    while active:
+        mask = np.zeros(nG, np.uint8)
+        mask[active] = 1
+        e.set_active(mask)
+        noise = np.zeros((nG, 48))
+        acts = np.full(nG, -1, np.int16)
+        for i in active:                       # one Dirichlet draw and one move per active game, in order
+            noise[i] = d["dirichlet"][di]
+            di += 1
+        e.search_with(evaluate, S, noise=noise)
+        for i in active:
+            acts[i] = d["choices"][ci]
+            ci += 1
+        e.play_move(0, add_noise=False, actions=acts, restart_finished=False)
+        for i in active:
+            pos[i] = orc.step_action(pos[i], int(acts[i]))
+        active = [i for i in active if not orc.is_terminal(pos[i])]
+    assert di == len(d["dirichlet"]) and ci == len(d["choices"])
+    st = e.stats()
+    assert st["games_finished"] == nG and st["moves"] == len(d["choices"])
+    n = int(d["n_examples"])
+    assert e.samples_pending() == n
+    s, p, wl = [x.cpu().numpy() for x in e.drain_samples()]
+    want_s = np.unpackbits(d["states"])[: n * 192].reshape(n, 3, 8, 8).astype(np.float32)
+    assert np.array_equal(s, want_s)
+    assert np.array_equal(p.view(np.uint32), d["policies"].view(np.uint32))
+    assert np.array_equal(wl, d["wls"])
