@@ -77,6 +77,7 @@ _SIGNATURES = {
     "az_net_max_batch": [_VP],
     "az_net_load_state": [_VP, _VP, C.c_int64],
     "az_net_forward": [_VP, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, _VP],
+    "az_net_forward_noalloc": [_VP, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, _VP],
     "az_net_forward_planes": [_VP, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP],
     "az_net_set_timing": [_VP, C.c_int32],
     "az_net_set_tower_form": [_VP, C.c_int32],

@@ -29,6 +29,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "az_common.h"
@@ -1232,6 +1233,44 @@ __global__ void k_planes_to_bits(const float* planes, int B, uint64_t* mine, uin
 using namespace az;
 
 // ---------------------------------------------------------------------------
+// Head buffers of one forward: tiled head activations and split-K partial sums.
+struct HeadBuffers {
+    __bf16 *p_act, *v_act;
+    float *part_p, *part_v;
+};
+
+// az_net_forward_noalloc keeps those buffers in device memory that belongs to the loaded
+// library instead of memory obtained from hipMalloc: room for AZ_NET_NOALLOC_MAX_BATCH
+// positions (6.75 MiB; every GPU the library runs on holds its own copy until the process
+// ends).  In host code the array's name is only a handle for hipGetSymbolAddress: the
+// device address is looked up once per device, in az_net_create with that device
+// current, and every launch is given that address.
+constexpr size_t NOALLOC_B = AZ_NET_NOALLOC_MAX_BATCH;
+static_assert(NOALLOC_B % 16 == 0, "whole head tiles");
+constexpr size_t NOALLOC_OFF_VACT = NOALLOC_B * POLICY_K * sizeof(__bf16);
+constexpr size_t NOALLOC_OFF_PARTP = NOALLOC_OFF_VACT + NOALLOC_B * VALUE_K * sizeof(__bf16);
+constexpr size_t NOALLOC_OFF_PARTV = NOALLOC_OFF_PARTP + (size_t)POLICY_CHUNKS * NOALLOC_B * NUM_ACTIONS * sizeof(float);
+constexpr size_t NOALLOC_BYTES = NOALLOC_OFF_PARTV + (size_t)VALUE_CHUNKS * NOALLOC_B * 128 * sizeof(float);
+static __device__ __align__(256) unsigned char scratch[NOALLOC_BYTES];
+
+constexpr int MAX_DEVICES = 64;
+static unsigned char* g_scratch_ptr[MAX_DEVICES];   // device address of `scratch` on each device, 0 = not asked yet
+static std::mutex g_scratch_mutex;
+
+// The calling thread's current device must be `device`.
+static int scratch_address(int device, unsigned char** out) {
+    AZ_CHECK_ARG(device >= 0 && device < MAX_DEVICES, "device ordinal %d out of range", device);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* ptr = nullptr;
+        AZ_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) AZ_FAIL(AZ_ERR_HIP, "hipGetSymbolAddress returned a null address for the static head buffers");
+        g_scratch_ptr[device] = (unsigned char*)ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return AZ_OK;
+}
+
 struct az_net {
     int blocks = 0, max_batch = 0, device = 0;
     bool loaded = false;
@@ -1250,6 +1289,7 @@ struct az_net {
     int64_t launches = 0;
     int ev_used = 0;
     std::vector<hipEvent_t> ev0, ev1;
+    HeadBuffers own() const { return HeadBuffers{p_act, v_act, part_p, part_v}; }
 };
 constexpr int TIMING_POOL = 512, TIMING_STRIDE = 8;
 
@@ -1340,7 +1380,8 @@ extern "C" int az_net_create(az_net** out, const az_net_config* cfg) {
     n->max_batch = cfg->max_batch;
     n->device = device;
     const size_t nb = n->blocks, nconv = 2 * nb + 1, B = n->max_batch;
-    int rc = AZ_OK;
+    unsigned char* static_buffers = nullptr;
+    int rc = scratch_address(device, &static_buffers);   // once per device, while it is current
 #define A(ptr, cnt) if (rc == AZ_OK) rc = dev_alloc(n, n->ptr, (cnt))
     A(stem_w, 2 * 4 * 64 * 16); A(stem_b, CH);
     A(conv_w, nconv * CONV_BYTES); A(conv_b, (nconv + 1) * CH);  // + one zero row
@@ -1512,18 +1553,17 @@ extern "C" int az_net_load_state(az_net* n, const float* s, int64_t count) {
     return AZ_OK;
 }
 
-// tower + head GEMMs: leaves the split-K partial sums in the network's buffers
-int az::net_forward_partial(az_net* n, int32_t B, const uint64_t* mine_dev, const uint64_t* theirs_dev,
-                            const int32_t* gather_dev, hipStream_t s) {
+// tower + head GEMMs: leaves the split-K partial sums in hb
+static int forward_partial(az_net* n, int32_t B, const uint64_t* mine_dev, const uint64_t* theirs_dev,
+                           const int32_t* gather_dev, const HeadBuffers& hb, hipStream_t s) {
     AZ_CHECK_ARG(n && n->loaded, "az_net_forward: network has no weights (call az_net_load_state)");
-    AZ_CHECK_ARG(B >= 0 && B <= n->max_batch, "az_net_forward: batch %d exceeds max_batch %d", B, n->max_batch);
     if (B == 0) return AZ_OK;
     AZ_CHECK_ARG(mine_dev && theirs_dev, "az_net_forward: null pointer");
     TowerParams tp;
     tp.mine = mine_dev; tp.theirs = theirs_dev; tp.gather = gather_dev; tp.B = B; tp.blocks = n->blocks;
     tp.stem_w = n->stem_w; tp.stem_b = n->stem_b; tp.conv_w = n->conv_w; tp.conv_b = n->conv_b;
     tp.se_img = n->se_img;
-    tp.value_w = n->value_w; tp.value_b = n->value_b; tp.p_act = n->p_act; tp.v_act = n->v_act;
+    tp.value_w = n->value_w; tp.value_b = n->value_b; tp.p_act = hb.p_act; tp.v_act = hb.v_act;
     static const int dbg = getenv("AZ_TOWER_DBG") ? atoi(getenv("AZ_TOWER_DBG")) : 0;
     tp.dbg = dbg;
     tp.stamps = n->stamps;
@@ -1540,27 +1580,45 @@ int az::net_forward_partial(az_net* n, int32_t B, const uint64_t* mine_dev, cons
     else if (form == 8) hipLaunchKernelGGL((k_tower_split<2, 8>), dim3((B + 3) / 4), dim3(512), 0, s, tp);
     else hipLaunchKernelGGL(k_tower, dim3((B + 3) / 4), dim3(256), 0, s, tp);
     if (stamp) AZ_HIP(hipEventRecord(n->ev1[n->ev_used++], s));
-    HeadParams hp{n->p_act, n->v_act, n->wp, n->wv, n->part_p, n->part_v, B};
+    HeadParams hp{hb.p_act, hb.v_act, n->wp, n->wv, hb.part_p, hb.part_v, B};
     hipLaunchKernelGGL(k_head_gemm, dim3((B + 16 * HEAD_MT - 1) / (16 * HEAD_MT), POLICY_CHUNKS + VALUE_CHUNKS), dim3(256), 0, s, hp);
     AZ_HIP(hipGetLastError());
     return AZ_OK;
 }
 
-az::FinishParams az::net_finish_params(az_net* n, int32_t B) {
-    return FinishParams{n->part_p, n->part_v, n->bp, n->bv1, n->wv2, n->bv2, nullptr, nullptr, nullptr, nullptr, B};
+static FinishParams finish_params(az_net* n, int32_t B, const HeadBuffers& hb) {
+    return FinishParams{hb.part_p, hb.part_v, n->bp, n->bv1, n->wv2, n->bv2, nullptr, nullptr, nullptr, nullptr, B};
 }
 
-int az::net_forward_full(az_net* n, int32_t B, const uint64_t* mine_dev, const uint64_t* theirs_dev,
-                         const int32_t* gather_dev, float* probs_dev, float* value_dev, float* policy_logits_dev,
-                         float* wl_logits_dev, hipStream_t s) {
-    const int rc = az::net_forward_partial(n, B, mine_dev, theirs_dev, gather_dev, s);
+static int forward_full(az_net* n, int32_t B, const uint64_t* mine_dev, const uint64_t* theirs_dev,
+                        const int32_t* gather_dev, const HeadBuffers& hb, float* probs_dev, float* value_dev,
+                        float* policy_logits_dev, float* wl_logits_dev, hipStream_t s) {
+    const int rc = forward_partial(n, B, mine_dev, theirs_dev, gather_dev, hb, s);
     if (rc != AZ_OK || B == 0) return rc;
     AZ_CHECK_ARG(probs_dev && value_dev, "az_net_forward: null pointer");
-    FinishParams fp = az::net_finish_params(n, B);
+    FinishParams fp = finish_params(n, B, hb);
     fp.probs = probs_dev; fp.value = value_dev; fp.policy_logits = policy_logits_dev; fp.wl_logits = wl_logits_dev;
     hipLaunchKernelGGL(k_head_finish, dim3((B + 3) / 4), dim3(256), 0, s, fp);
     AZ_HIP(hipGetLastError());
     return AZ_OK;
+}
+
+int az::net_forward_partial(az_net* n, int32_t B, const uint64_t* mine_dev, const uint64_t* theirs_dev,
+                            const int32_t* gather_dev, hipStream_t s) {
+    AZ_CHECK_ARG(n, "az_net_forward: null network");
+    AZ_CHECK_ARG(B >= 0 && B <= n->max_batch, "az_net_forward: batch %d exceeds max_batch %d", B, n->max_batch);
+    return forward_partial(n, B, mine_dev, theirs_dev, gather_dev, n->own(), s);
+}
+
+az::FinishParams az::net_finish_params(az_net* n, int32_t B) { return finish_params(n, B, n->own()); }
+
+int az::net_forward_full(az_net* n, int32_t B, const uint64_t* mine_dev, const uint64_t* theirs_dev,
+                         const int32_t* gather_dev, float* probs_dev, float* value_dev, float* policy_logits_dev,
+                         float* wl_logits_dev, hipStream_t s) {
+    AZ_CHECK_ARG(n, "az_net_forward: null network");
+    AZ_CHECK_ARG(B >= 0 && B <= n->max_batch, "az_net_forward: batch %d exceeds max_batch %d", B, n->max_batch);
+    return forward_full(n, B, mine_dev, theirs_dev, gather_dev, n->own(), probs_dev, value_dev, policy_logits_dev,
+                        wl_logits_dev, s);
 }
 
 extern "C" int az_net_forward(az_net* n, int32_t B, const uint64_t* mine_dev, const uint64_t* theirs_dev,
@@ -1568,6 +1626,31 @@ extern "C" int az_net_forward(az_net* n, int32_t B, const uint64_t* mine_dev, co
                               float* wl_logits_dev, void* stream) {
     return az::net_forward_full(n, B, mine_dev, theirs_dev, nullptr, probs_dev, value_dev, policy_logits_dev,
                                 wl_logits_dev, (hipStream_t)stream);
+}
+
+// az_net_forward for callers that may not allocate.  The head activations and the split-K
+// partial sums of this call live in the library's static device array, so the batch is
+// bounded by AZ_NET_NOALLOC_MAX_BATCH whatever max_batch the network was created with.
+// Nothing in that array has to start at zero: every element a kernel reads was written by
+// the tower or the head GEMM of the same call (rows past B in the last 16-position tile
+// feed only output rows that are never stored).
+extern "C" int az_net_forward_noalloc(az_net* n, int32_t B, const uint64_t* mine_dev, const uint64_t* theirs_dev,
+                                      float* probs_dev, float* value_dev, float* policy_logits_dev,
+                                      float* wl_logits_dev, void* stream) {
+    AZ_CHECK_ARG(n, "az_net_forward_noalloc: null network");
+    AZ_CHECK_ARG(B >= 0, "az_net_forward_noalloc: negative batch %d", B);
+    AZ_CHECK_ARG(B <= AZ_NET_NOALLOC_MAX_BATCH,
+                 "az_net_forward_noalloc: batch %d exceeds the static buffers' %d positions (use az_net_forward)", B,
+                 AZ_NET_NOALLOC_MAX_BATCH);
+    unsigned char* base = (n->device >= 0 && n->device < MAX_DEVICES) ? g_scratch_ptr[n->device] : nullptr;
+    if (!base) AZ_FAIL(AZ_ERR_STATE, "az_net_forward_noalloc: the static buffers of device %d were never located", n->device);
+    HeadBuffers hb;
+    hb.p_act = reinterpret_cast<__bf16*>(base);
+    hb.v_act = reinterpret_cast<__bf16*>(base + NOALLOC_OFF_VACT);
+    hb.part_p = reinterpret_cast<float*>(base + NOALLOC_OFF_PARTP);
+    hb.part_v = reinterpret_cast<float*>(base + NOALLOC_OFF_PARTV);
+    return forward_full(n, B, mine_dev, theirs_dev, nullptr, hb, probs_dev, value_dev, policy_logits_dev, wl_logits_dev,
+                        (hipStream_t)stream);
 }
 
 extern "C" int az_net_forward_planes(az_net* n, int32_t B, const float* planes_dev, float* probs_dev,

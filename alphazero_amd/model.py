@@ -179,6 +179,14 @@ class HipInference:
                                                  self._p(value), self._p(pl), self._p(wl), stream))
         return probs, value, pl, wl
 
+    def forward_bits_into(self, mine, theirs, probs, value, policy_logits=None, wl_logits=None):
+        """az_net_forward_noalloc: like forward_bits for at most 256 positions, writing into
+        tensors the caller already owns; neither this wrapper nor the library allocates."""
+        B = mine.numel()
+        _lib.check(_lib.lib().az_net_forward_noalloc(
+            self.h, B, self._p(mine), self._p(theirs), self._p(probs), self._p(value), self._p(policy_logits),
+            self._p(wl_logits), C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+
     def forward_planes(self, planes, want_logits=False):
         """planes: [B,3,8,8] float32 cuda tensor of encoded states."""
         assert planes.dtype == torch.float32 and planes.is_contiguous() and tuple(planes.shape[1:]) == (3, 8, 8)

@@ -84,7 +84,22 @@ int az_net_load_state(az_net* n, const float* state_host, int64_t count);
 int az_net_forward(az_net* n, int32_t B, const uint64_t* mine_dev, const uint64_t* theirs_dev,
                    float* probs_dev, float* value_dev, float* policy_logits_dev,
                    float* wl_logits_dev, void* stream);
-/* Same, from the reference's float planes [B][3][8][8]; fails with AZ_ERR_ARG
+/* az_net_forward without any allocation.  No counterpart in the reference: it is for
+ * callers that cannot call hipMalloc (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid it).  The head activations and split-K partial sums of the call,
+ * which az_net_forward keeps in buffers az_net_create allocated, live here in a static
+ * device array inside the library (6.75 MiB on every GPU the library is used on, held
+ * until the process ends), so B is limited to AZ_NET_NOALLOC_MAX_BATCH whatever max_batch
+ * the network has; a larger B fails with AZ_ERR_ARG.  Inputs, outputs and results are
+ * those of az_net_forward, bit for bit.  Every call on a GPU shares that GPU's array:
+ * calls that overlap on one GPU (two streams, two threads, two networks) race.  The
+ * network must have been created and loaded beforehand (that is where the weights are
+ * allocated and the array's device address is looked up). */
+#define AZ_NET_NOALLOC_MAX_BATCH 256
+int az_net_forward_noalloc(az_net* n, int32_t B, const uint64_t* mine_dev, const uint64_t* theirs_dev,
+                           float* probs_dev, float* value_dev, float* policy_logits_dev,
+                           float* wl_logits_dev, void* stream);
+/* Same as az_net_forward, from the reference's float planes [B][3][8][8]; fails with AZ_ERR_ARG
  * if the input is not an encoded state (0/1 planes, third plane all ones).
  * Synchronises the stream. */
 int az_net_forward_planes(az_net* n, int32_t B, const float* planes_dev, float* probs_dev,
