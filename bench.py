@@ -7,16 +7,24 @@ Workload (BASELINE config 4, per GPU): 1024 concurrent Breakthrough games,
 800 simulations per move, Dirichlet noise on, SE-ResNet 20x128 with random-init
 weights, tree reuse, finished games restart so the batch stays full.  One step
 = one ply of every game = 1024 x 800 simulations.  For N > 1 the games are
-sharded (one process per GPU, rank-offset seeds, no data-path collective).
+sharded (one process per GPU, rank-offset seeds, no data-path collective);
+started without a launcher (WORLD_SIZE unset) the script starts its own N ranks
+with torch.distributed.run before it touches a GPU and relays rank 0's line.
 
 Rank 0 prints one JSON line.  `roofline` prices the dominant kernel (the fused
 SE-ResNet tower) against the dense bf16 MFMA peak using HIP-event timings taken
-inside the timed region; `cpu_baseline` times the CPU oracle (C tree + float32
-torch forward) on a bounded sample of the same workload on the host cores.
+inside the timed region.  `cpu_baseline` times the CPU oracle (C tree + float32
+torch forward) as P independent single-thread processes x 128 games playing
+the same self-play loop on the host cores, before the GPU is touched.
+`secondary` (N = 1) times the move-generation kernel (BASELINE config 2) and
+the batch-4096 network forward (config 3) with HIP events after the timed
+region; it does not enter `value`.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,6 +35,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_PER_POSITION = 778_732_032          # whole 20x128 network, 2*MAC
+PEAK_BF16_DENSE = 2.5e15
+PEAK_HBM = 8.0e12
+MOVEGEN_BYTES_PER_POSITION = 42          # 17 in (2 x u64 + turn) + 24 legal3 + 1 status
 
 
 def tower_flop_per_position(blocks):
@@ -37,45 +48,224 @@ def tower_flop_per_position(blocks):
     return 2 * 64 * 128 * 27 + blocks * (2 * conv + 12_288) + conv + 2 * 64 * 32 * 128
 
 
-PEAK_BF16_DENSE = 2.5e15
+def network_flop_per_position(blocks):
+    """Tower + the three head FCs (policy 8192x192, value 2048x128, 128x2)."""
+    return tower_flop_per_position(blocks) + 2 * (8192 * 192 + 2048 * 128 + 128 * 2)
 
 
-def cpu_baseline(games, sims_budget_s, blocks, cores):
-    """Reference-equivalent CPU path: oracle tree (oracle/az_oracle.c) + float32
-    torch forward, one search_batch from the start position with noise."""
+# ----------------------------------------------------------------------------
+# CPU baseline: the reference's execute_parallel_episodes (src/parallel_trainer.py:137-223)
+# restated over the C oracle, one single-thread process per host core.
+
+def cpu_worker(games, sims, blocks, seconds, seed):
+    """One process: `games` games in lock-step, `sims` simulations per move, root noise,
+    temperature schedule, finished games leave the batch; plays until `seconds` are over.
+    Prints {"sims": .., "moves": .., "evals": .., "seconds": ..}."""
     from oracle import oracle as orc
     from alphazero_amd.model import AlphaZeroNet
-    torch.set_num_threads(cores)
+    torch.set_num_threads(1)
     torch.manual_seed(0)
     model = AlphaZeroNet(num_blocks=blocks, num_filters=128).eval()
     m = orc.OracleMCTS(games, c_puct=1.5)
+    rs = np.random.RandomState(seed)
     for g in range(games):
         m.set_game(g, orc.start_position())
+    evals = 0
 
     def evaluate(planes, need):
-        with torch.no_grad():
-            pl, wl = model(torch.from_numpy(planes))
-            probs = torch.softmax(pl, dim=1).numpy()
-            wlp = torch.softmax(wl, dim=1).numpy()
-        return probs, wlp[:, 0] - wlp[:, 1]
-    rs = np.random.RandomState(0)
-    m.roots_prepare()
-    probs, _ = evaluate(m.planes, m.need)
-    m.roots_expand(probs)
-    m.add_noise(rs.dirichlet([0.35] * 48, size=games), 0.25)
+        nonlocal evals
+        rows = np.flatnonzero(need)
+        probs = np.zeros((games, 192), np.float32)
+        values = np.zeros(games, np.float32)
+        if len(rows):
+            with torch.no_grad():
+                pl, wl = model(torch.from_numpy(planes[rows]))
+                probs[rows] = torch.softmax(pl, dim=1).numpy()
+                wlp = torch.softmax(wl, dim=1).numpy()
+            values[rows] = wlp[:, 0] - wlp[:, 1]
+            evals += len(rows)
+        return probs, values
+
+    active = np.ones(games, np.uint8)
+    plies = np.zeros(games, np.int64)
+    sims_done = moves = 0
     t0 = time.perf_counter()
-    sims = 0
-    while True:
-        m.select()
-        probs, values = evaluate(m.planes, m.need)
-        m.expand_backup(probs, values)
-        sims += games
-        if time.perf_counter() - t0 > sims_budget_s:
+    deadline = t0 + seconds
+    while active.any() and time.perf_counter() < deadline:
+        m.set_active(active)
+        if m.roots_prepare():
+            probs, _ = evaluate(m.planes, m.need)
+            m.roots_expand(probs)
+        m.add_noise(rs.dirichlet([0.35] * 48, size=games), 0.25)
+        n_active = int(active.sum())
+        done = 0
+        while done < sims and time.perf_counter() < deadline:
+            m.select()
+            probs, values = evaluate(m.planes, m.need)
+            m.expand_backup(probs, values)
+            sims_done += n_active
+            done += 1
+        if done < sims:
             break
-    dt = time.perf_counter() - t0
-    return dict(value=sims / dt, unit="sims/s", cores=cores, kind="port",
-                sample=f"{games} games x {sims // games} simulations of one search_batch from the start "
-                       f"position (noise on), C oracle tree + fp32 torch forward {blocks}x128, {dt:.1f} s")
+        for g in np.flatnonzero(active):
+            probs = m.action_probs(int(g), 1.0 if plies[g] < 16 else 0.0).astype(np.float64)
+            a = int(rs.choice(192, p=probs / probs.sum()))
+            m.advance(int(g), a)
+            plies[g] += 1
+            moves += 1
+            if orc.is_terminal(m.get_game(int(g))):
+                active[g] = 0
+    print(json.dumps({"sims": sims_done, "moves": moves, "evals": evals,
+                      "seconds": time.perf_counter() - t0}), flush=True)
+
+
+def host_cores():
+    """Cores this job may use: the affinity mask, capped by the pool's per-job share when the
+    environment states one (OMP_NUM_THREADS is set to it on the GPU boxes, where the
+    affinity mask still shows the whole machine)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    share = os.environ.get("OMP_NUM_THREADS", "")
+    if share.isdigit() and int(share) > 0:
+        n = min(n, int(share))
+    return max(1, n)
+
+
+def cpu_baseline(sims, blocks, seconds, games=128, procs=None):
+    """P = host cores independent processes x 128 games, one torch thread each.  Runs before
+    this process touches the GPU."""
+    P = procs or host_cores()
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(i), "--sims", str(sims),
+                               "--blocks", str(blocks), "--cpu-seconds", str(seconds), "--games", str(games)],
+                              stdout=subprocess.PIPE, env=env, cwd=ROOT) for i in range(P)]
+    rows = []
+    for p in procs:
+        out, _ = p.communicate()
+        if p.returncode == 0 and out.strip():
+            rows.append(json.loads(out.decode().strip().splitlines()[-1]))
+    wall = time.perf_counter() - t0
+    if not rows:
+        return {"error": "no CPU worker finished"}
+    total_sims = sum(r["sims"] for r in rows)
+    span = max(r["seconds"] for r in rows)
+    moves = sum(r["moves"] for r in rows)
+    return dict(value=total_sims / span, unit="sims/s", cores=len(rows), kind="port",
+                positions_per_sec=moves / span if moves else total_sims / span / sims,
+                positions_per_sec_is="measured moves/s" if moves else f"sims/s / {sims} (no move completed inside the sample)",
+                sample=f"P = {len(rows)} independent processes (one per host core of this job's share, 1 torch thread "
+                       f"each) x {games} games of the reference's self-play loop from the start position, {sims} "
+                       f"sims/move, Dirichlet noise, C oracle tree + fp32 torch forward {blocks}x128, {span:.1f} s "
+                       f"of play per process ({wall:.1f} s wall with start-up), {total_sims} simulations in total")
+
+
+# ----------------------------------------------------------------------------
+# Secondary measurements: BASELINE configs 2 and 3 (HIP events on the launch stream)
+
+def secondary_block(blocks):
+    import ctypes as C
+    from alphazero_amd import _lib
+    from alphazero_amd.game import movegen_encode
+    from alphazero_amd.model import AlphaZeroNet, HipInference
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from movegen_bench import random_positions
+    out = {}
+    dev = torch.device("cuda", torch.cuda.current_device())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda x: C.c_void_p(x.data_ptr())
+    base_w, base_b, base_t = random_positions(1_000_000, seed=1)
+    for label, n, iters in (("movegen_1M", 1_000_000, 200), ("movegen_64M", 64_000_000, 20)):
+        rep = (n + base_w.numel() - 1) // base_w.numel()
+        w, b, t = (x.repeat(rep)[:n].contiguous() for x in (base_w, base_b, base_t))
+        legal3 = torch.empty((n, 3), dtype=torch.int64, device=dev)
+        status = torch.empty(n, dtype=torch.int8, device=dev)
+
+        def run():
+            _lib.check(_lib.lib().az_movegen_encode(n, p(w), p(b), p(t), p(legal3), None, None, p(status), st))
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        sec = e0.elapsed_time(e1) * 1e-3 / iters
+        gbs = n * MOVEGEN_BYTES_PER_POSITION / sec
+        out[label] = {"kernel": "movegen_kernel<false,false>", "positions": n, "us_per_launch": sec * 1e6,
+                      "positions_per_sec": n / sec, "bytes_per_position": MOVEGEN_BYTES_PER_POSITION,
+                      "achieved_GBps": gbs / 1e9, "peak_GBps": PEAK_HBM / 1e9, "frac": gbs / PEAK_HBM,
+                      "launches_timed": iters,
+                      "note": "1 M positions = 42 MB sit inside the 256 MB Infinity Cache; the 64 M figure is the HBM one"
+                      if n <= 4_000_000 else "2.7 GB working set: HBM-resident"}
+        del w, b, t, legal3, status
+    # config 3: batch-4096 forward on 4096 of those positions
+    B = 4096
+    r = movegen_encode(base_w[:B].cpu().numpy().view(np.uint64), base_b[:B].cpu().numpy().view(np.uint64),
+                       base_t[:B].cpu().numpy(), want_mask=False, want_planes=True)
+    planes = r["planes"].cpu().numpy().reshape(B, 3, 64) > 0.5
+    weights = np.uint64(1) << np.arange(64, dtype=np.uint64)
+    mine = torch.from_numpy((planes[:, 0].astype(np.uint64) * weights).sum(1, dtype=np.uint64).view(np.int64)).to(dev)
+    theirs = torch.from_numpy((planes[:, 1].astype(np.uint64) * weights).sum(1, dtype=np.uint64).view(np.int64)).to(dev)
+    torch.manual_seed(0)
+    inf = HipInference(AlphaZeroNet(num_blocks=blocks, num_filters=128).eval(), max_batch=B)
+    for _ in range(3):
+        inf.forward_bits(mine, theirs)
+    torch.cuda.synchronize()
+    iters = 30
+    inf.set_timing(True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        inf.forward_bits(mine, theirs)
+    e1.record()
+    torch.cuda.synchronize()
+    tower_ms, tower_n = inf.tower_time()
+    sec = e0.elapsed_time(e1) * 1e-3 / iters
+    flop = network_flop_per_position(blocks) * B
+    out["forward_4096"] = {"kernels": "k_tower + k_head_gemm + k_head_finish", "batch": B, "ms_per_forward": sec * 1e3,
+                           "positions_per_sec": B / sec, "flop_per_position": network_flop_per_position(blocks),
+                           "achieved_TFLOPs": flop / sec / 1e12, "peak_TFLOPs": PEAK_BF16_DENSE / 1e12,
+                           "frac": flop / sec / PEAK_BF16_DENSE, "tower_ms": tower_ms, "tower_samples": tower_n,
+                           "tower_frac": (tower_flop_per_position(blocks) * B / (tower_ms * 1e-3) / PEAK_BF16_DENSE) if tower_ms else None,
+                           "forwards_timed": iters}
+    inf.close()
+    return out
+
+
+# ----------------------------------------------------------------------------
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """N > 1 without a launcher: start the N ranks as child processes of this one, which has
+    made no GPU call, relay rank 0's JSON line and exit with the launcher's status."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, cwd=os.getcwd())
+    line = None
+    for raw in proc.stdout:
+        text = raw.decode(errors="replace")
+        if text.lstrip().startswith('{"metric"'):
+            line = text.strip()
+        else:
+            sys.stderr.write(text)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 1
+        sys.stderr.write("bench.py: the ranks exited without printing a result line\n")
+    raise SystemExit(rc)
 
 
 def main():
@@ -87,20 +277,39 @@ def main():
     ap.add_argument("--sims", type=int, default=800, help="simulations per move")
     ap.add_argument("--blocks", type=int, default=20)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="0 disables the CPU baseline leg")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the config 2 / config 3 measurements")
+    ap.add_argument("--exchange-only", action="store_true",
+                    help="N > 1: time only the two exchange steps (sample all-gather, data-parallel training "
+                         "step); no self-play, value = 0.  With AZ_BENCH_BACKEND=gloo this needs no GPU")
+    ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.cpu_worker is not None:
+        cpu_worker(args.games, args.sims, args.blocks, args.cpu_seconds, 1000 + args.cpu_worker)
+        return
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if not torch.cuda.is_available():
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    # CPU leg first: its worker processes are started while this process has made no GPU call
+    cpu = None
+    if world == 1 and args.cpu_seconds > 0:
+        cpu = cpu_baseline(args.sims, args.blocks, args.cpu_seconds)
+
+    backend = os.environ.get("AZ_BENCH_BACKEND", "nccl")
+    rehearsal = backend != "nccl"
+    have_gpu = torch.cuda.is_available()
+    if not have_gpu and not (args.exchange_only and rehearsal):
         raise SystemExit("bench.py needs a GPU: the self-play engine has no CPU fallback")
     # AZ_BENCH_BACKEND=gloo rehearses the N > 1 control flow on a box with one GPU: every
     # rank then shares cuda:0 and the collectives run on CPU tensors.
-    backend = os.environ.get("AZ_BENCH_BACKEND", "nccl")
-    rehearsal = backend != "nccl"
-    torch.cuda.set_device(0 if rehearsal else local_rank)
+    if have_gpu:
+        torch.cuda.set_device(0 if rehearsal else local_rank)
     coll_dev = "cpu" if rehearsal else "cuda"
     dist = None
     if world > 1:
@@ -116,32 +325,42 @@ def main():
 
     torch.manual_seed(0)                       # same random-init weights on every rank
     model = AlphaZeroNet(num_blocks=args.blocks, num_filters=128).eval()
-    sp = SelfPlay(model, n_games=args.games, num_simulations=args.sims, seed=1234 + rank)
-    eng, inf = sp.engine, sp.inference
 
     def barrier():
-        torch.cuda.synchronize()
+        if have_gpu:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if have_gpu:
+            torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        sp.step(restart_finished=True)
-    barrier()
-    st0 = eng.stats()
-    inf.set_timing(True)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        sp.step(restart_finished=True)
-        # long runs: hand the finished games' samples over before the device queue fills
-        # (on the device, as a trainer would take them; part of the timed work)
-        if (i + 1) % 16 == 0 and eng.samples_pending() > 32768:
-            eng.drain_samples()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    tower_ms, tower_samples = inf.tower_time()
-    inf.set_timing(False)
-    st1 = eng.stats()
+    if args.exchange_only:
+        if dist is None:
+            raise SystemExit("--exchange-only needs --gpus N with N > 1")
+        sp = eng = inf = None
+        st0 = st1 = dict(simulations=0, moves=0, nn_evals=0)
+        dt, tower_ms, tower_samples, depth = 1.0, 0.0, 0, 0.0
+    else:
+        sp = SelfPlay(model, n_games=args.games, num_simulations=args.sims, seed=1234 + rank)
+        eng, inf = sp.engine, sp.inference
+        for _ in range(args.warmup):
+            sp.step(restart_finished=True)
+        barrier()
+        st0 = eng.stats()
+        inf.set_timing(True)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            sp.step(restart_finished=True)
+            # long runs: hand the finished games' samples over before the device queue fills
+            # (on the device, as a trainer would take them; part of the timed work)
+            if (i + 1) % 16 == 0 and eng.samples_pending() > 32768:
+                eng.drain_samples()
+        barrier()
+        dt = time.perf_counter() - t0
+        tower_ms, tower_samples = inf.tower_time()
+        inf.set_timing(False)
+        st1 = eng.stats()
+        depth = eng.mean_depth()
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -156,51 +375,23 @@ def main():
 
     exchange = None
     if dist is not None:
-        # The two exchange steps of an iteration, timed outside the self-play region on a
-        # synthetic iteration's worth of samples (games x 64 plies per rank):
-        # RCCL all-gather into every rank's replay buffer, then one data-parallel
-        # training step at global batch 1024 with an RCCL gradient all-reduce.
-        try:
-            from alphazero_amd.distributed import all_gather_samples, train_step
-            n_s = args.games * 64
-            g = torch.Generator(device=coll_dev).manual_seed(rank)
-            s_states = (torch.rand((n_s, 3, 8, 8), device=coll_dev, generator=g) > 0.7).float()
-            s_pis = torch.softmax(torch.rand((n_s, 192), device=coll_dev, generator=g), 1)
-            s_wls = torch.tensor([[1.0, 0.0]], device=coll_dev).repeat(n_s, 1)
-            barrier()
-            t1 = time.perf_counter()
-            G = all_gather_samples(s_states, s_pis, s_wls)
-            torch.cuda.synchronize()
-            t_gather = time.perf_counter() - t1
-            train_model = AlphaZeroNet(num_blocks=args.blocks, num_filters=128).to(coll_dev)
-            train_model.load_state_dict(model.state_dict())
-            opt = torch.optim.Adam(train_model.parameters(), lr=1e-3, weight_decay=1e-4)
-            per = max(1, 1024 // world)
-            lo = rank * per
-            batch = (G[0][lo:lo + per], G[1][lo:lo + per], G[2][lo:lo + per])
-            del G
-            train_step(train_model, opt, *batch)          # warm-up (allocator, RCCL channels)
-            barrier()
-            t1 = time.perf_counter()
-            train_step(train_model, opt, *batch)
-            torch.cuda.synchronize()
-            t_train = time.perf_counter() - t1
-            tt = torch.tensor([t_gather, t_train], dtype=torch.float64, device=coll_dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            exchange = {"sample_allgather_ms": float(tt[0]) * 1e3, "samples_per_rank": n_s,
-                        "bytes_per_rank": n_s * 1544, "train_step_ms": float(tt[1]) * 1e3,
-                        "train_global_batch": per * world, "backend": backend}
-        except Exception as exc:  # the self-play line must still be printed
-            exchange = {"error": repr(exc)}
+        exchange = exchange_block(args, dist, model, rank, world, coll_dev, backend, barrier)
 
     if rank == 0:
-        flop_launch = tower_flop_per_position(args.blocks) * args.games
+        # rows the tower computed vs rows whose result was used: every launch of the timed
+        # region carried `games` rows; a row whose leaf was terminal needs no evaluation
+        rows_launched = float(args.steps) * (args.sims + 1) * args.games * world
+        used_fraction = min(1.0, evals / rows_launched) if rows_launched else 0.0
+        flop_launch = tower_flop_per_position(args.blocks) * args.games * used_fraction
         # HBM-side bytes per tower launch come from separate rocprofv3 --pmc passes
         # (profiles/): counters cannot be read from inside this process
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_k_tower_pmc.json")
-        if os.path.exists(pmc) and args.games == 1024 and args.blocks == 20:
-            traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
+        traffic, traffic_source = None, None
+        for name in ("r02_k_tower_pmc.json", "r01_k_tower_pmc.json"):
+            pmc = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(pmc) and args.games == 1024 and args.blocks == 20:
+                traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
+                traffic_source = f"profiles/{name}: separate rocprofv3 --pmc passes of this workload, not this run"
+                break
         achieved = flop_launch / (tower_ms * 1e-3) if tower_ms > 0 else 0.0
         out = {
             "metric": "selfplay_mcts_simulations_per_sec",
@@ -223,19 +414,69 @@ def main():
                        "parallelism": f"games sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_BF16_DENSE / 1e12,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_DENSE, "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "kernel": "k_tower" if args.games > 512 else ("k_tower_split<2>" if args.games > 256 else "k_tower_split<1>"),
                          "launch_ms": tower_ms, "launch_samples": tower_samples,
                          "flop_per_launch": flop_launch,
-                         "mean_search_depth": eng.mean_depth()},
+                         "rows_per_launch": args.games, "rows_used_fraction": used_fraction,
+                         "mean_search_depth": depth},
         }
         if exchange is not None:
             out["exchange"] = exchange
-        if world == 1 and args.cpu_seconds > 0:
-            cores = min(16, os.cpu_count() or 1)
-            out["cpu_baseline"] = cpu_baseline(128, args.cpu_seconds, args.blocks, cores)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        if args.exchange_only:
+            out["config"]["workload"] = "exchange steps only (no self-play was run; value is 0 by construction)"
+        if world == 1 and not args.no_secondary:
+            del sp, eng, inf
+            torch.cuda.empty_cache()
+            try:
+                out["secondary"] = secondary_block(args.blocks)
+            except Exception as exc:           # the headline line must still be printed
+                out["secondary"] = {"error": repr(exc)}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def exchange_block(args, dist, model, rank, world, coll_dev, backend, barrier):
+    """The two exchange steps of an iteration, timed outside the self-play region on a
+    synthetic iteration's worth of samples (games x 64 plies per rank): all-gather into
+    every rank's replay buffer, then one data-parallel training step at global batch 1024
+    with a gradient all-reduce (RCCL when backend is nccl)."""
+    from alphazero_amd.model import AlphaZeroNet
+    try:
+        from alphazero_amd.distributed import all_gather_samples, train_step
+        n_s = args.games * 64
+        g = torch.Generator(device=coll_dev).manual_seed(rank)
+        s_states = (torch.rand((n_s, 3, 8, 8), device=coll_dev, generator=g) > 0.7).float()
+        s_pis = torch.softmax(torch.rand((n_s, 192), device=coll_dev, generator=g), 1)
+        s_wls = torch.tensor([[1.0, 0.0]], device=coll_dev).repeat(n_s, 1)
+        barrier()
+        t1 = time.perf_counter()
+        G = all_gather_samples(s_states, s_pis, s_wls)
+        barrier()
+        t_gather = time.perf_counter() - t1
+        train_model = AlphaZeroNet(num_blocks=args.blocks, num_filters=128).to(coll_dev)
+        train_model.load_state_dict(model.state_dict())
+        opt = torch.optim.Adam(train_model.parameters(), lr=1e-3, weight_decay=1e-4)
+        per = max(1, 1024 // world)
+        lo = rank * per
+        batch = (G[0][lo:lo + per], G[1][lo:lo + per], G[2][lo:lo + per])
+        del G
+        train_step(train_model, opt, *batch)          # warm-up (allocator, RCCL channels)
+        barrier()
+        t1 = time.perf_counter()
+        train_step(train_model, opt, *batch)
+        barrier()
+        t_train = time.perf_counter() - t1
+        tt = torch.tensor([t_gather, t_train], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return {"sample_allgather_ms": float(tt[0]) * 1e3, "samples_per_rank": n_s,
+                "bytes_per_rank": n_s * 1544, "train_step_ms": float(tt[1]) * 1e3,
+                "train_global_batch": per * world, "backend": backend}
+    except Exception as exc:  # the self-play line must still be printed
+        return {"error": repr(exc)}
 
 
 if __name__ == "__main__":

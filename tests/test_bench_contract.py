@@ -27,6 +27,31 @@ def test_flop_accounting(bench):
 
 
 def test_cpu_baseline_leg_runs(bench):
-    out = bench.cpu_baseline(games=4, sims_budget_s=0.5, blocks=1, cores=2)
+    """P single-thread processes playing the reference's self-play loop over the oracle."""
+    out = bench.cpu_baseline(sims=3, blocks=1, seconds=2.0, games=4, procs=2)
     assert out["kind"] == "port" and out["unit"] == "sims/s" and out["cores"] == 2
-    assert out["value"] > 0 and "4 games" in out["sample"]
+    assert out["value"] > 0 and "P = 2 independent processes" in out["sample"] and "4 games" in out["sample"]
+    assert out["positions_per_sec"] > 0
+
+
+def test_gpus_n_without_a_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset must start two ranks itself and relay one
+    JSON line.  Rehearsed here without a GPU: gloo backend, exchange steps only (the sample
+    all-gather and the data-parallel training step are real, the self-play region is skipped)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(AZ_BENCH_BACKEND="gloo", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--games", "4", "--blocks", "1", "--exchange-only"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["metric"] == "selfplay_mcts_simulations_per_sec"
+    ex = out["exchange"]
+    assert "error" not in ex, ex
+    assert ex["backend"] == "gloo" and ex["sample_allgather_ms"] > 0 and ex["train_step_ms"] > 0
+    assert ex["samples_per_rank"] == 4 * 64

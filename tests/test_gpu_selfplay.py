@@ -304,3 +304,27 @@ def test_fused_sample_stream_equals_the_reference_stream(golden_dir, small_model
     assert np.array_equal(s, want_s)
     assert np.array_equal(p.view(np.uint32), d["policies"].view(np.uint32))
     assert np.array_equal(wl, d["wls"])
+
+
+def test_bench_starts_its_own_ranks_on_the_gpu():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset: the script starts two ranks itself, both
+    play on this box's one GPU (gloo rehearsal of the collectives) and rank 0's single JSON
+    line is relayed with the whole-job counts."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["AZ_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--games", "32", "--sims", "16", "--blocks", "2", "--cpu-seconds", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak"
+    # two ranks x 32 games x 16 simulations x 2 plies
+    assert round(out["value"] * out["ms_per_step"] * 1e-3 * 2) == 2 * 32 * 16 * 2
+    assert "error" not in out["exchange"] and out["exchange"]["backend"] == "gloo"
