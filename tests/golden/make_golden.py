@@ -12,6 +12,10 @@ Outputs (all data, no code):
                      noisy roots with the recorded Dirichlet draws
     selfplay_tier.npz  execute_parallel_episodes stream with recorded RNG draws
     nn_tier.npz      float32 logits of seeded AlphaZeroNet instances
+    latency_tier.npz   MCTS.search(game, add_noise=False) with a fresh root at 200 simulations, the
+                     move arena.py / web.py pick from it, and one whole arena-style game
+    baseline_movegen_tier.npz  legal-move sets and terminal verdicts of the reference's second,
+                     independently written move generator (src/baseline/state.py)
 """
 import os
 import random
@@ -581,10 +585,133 @@ def make_train_tier():
     print("train tier done")
 
 
+# ------------------------------------------------------------------ latency (arena / web) tier
+def best_by_visits(root):
+    """The move rule of src/arena.py:257-262 and src/web.py:455-460: the first child in
+    insertion order with the strictly largest visit count."""
+    best_action, best_visits = -1, -1
+    for action, child in root.children.items():
+        if child.visit_count > best_visits:
+            best_visits = child.visit_count
+            best_action = action
+    return best_action
+
+
+def make_latency_tier(S=200):
+    """Arena.play_game (src/arena.py:248-265) and make_alphazero_move (src/web.py:447-470) call
+    MCTS.search(game, add_noise=False) with a fresh root for every move and play the most
+    visited child.  Ten roots searched that way, and one whole game played that way."""
+    roots_pos = tree_positions()
+    m = TableMCTS(None, num_simulations=S, c_puct=1.5)
+    out = {"sims": np.array(S)}
+    wb = [game_bits(g) for g in roots_pos]
+    out["white"] = np.array([x[0] for x in wb], np.uint64)
+    out["black"] = np.array([x[1] for x in wb], np.uint64)
+    out["turn"] = np.array([g.turn for g in roots_pos], np.int8)
+    st, best, val = [], [], []
+    for g in roots_pos:
+        before = (g.board.copy(), g.turn)
+        root = m.search(g, add_noise=False)
+        assert np.array_equal(before[0], g.board) and before[1] == g.turn      # the game is not touched
+        st.append(root_stats(root))
+        best.append(best_by_visits(root))
+        val.append(float(root.value()))                                      # web.py:463
+    for key in st[0]:
+        out[f"fresh_{key}"] = np.array([s[key] for s in st])
+    out["best_action"] = np.array(best, np.int16)
+    out["root_value"] = np.array(val, np.float64)
+    # one arena game: both sides the same table network, fresh root per move
+    g = BreakthroughGame()
+    played, visits = [], []
+    while not g.is_terminal():
+        root = m.search(g, add_noise=False)
+        a = best_by_visits(root)
+        played.append(a)
+        visits.append(root.children[a].visit_count)
+        g.step(g.decode_action(a))
+    w, l = g.get_result()
+    out["game_actions"] = np.array(played, np.int16)
+    out["game_best_visits"] = np.array(visits, np.uint32)
+    out["game_result"] = np.array([w, l], np.float32)
+    fw, fb = game_bits(g)
+    out["game_final"] = np.array([fw, fb], np.uint64)
+    np.savez_compressed(os.path.join(HERE, "latency_tier.npz"), **out)
+    print("latency tier:", len(roots_pos), "roots; arena game of", len(played), "plies, result", (w, l))
+
+
+# ------------------------------------------------------------------ second movegen oracle
+def make_baseline_movegen_tier():
+    """src/baseline/state.py is a second move generator, written independently of src/game.py
+    on bitboards (shifts by 7 / 8 / 9 with file masks); the reference's own
+    tests/test_compatibility.py:40-104 cross-checks the two.  Its move sets (from-square,
+    to-square on the real board), is_terminal and check_win for: the start position, the 20
+    sparse boards of that test for both sides, 400 positions from seeded random play, and
+    200 random boards of varying density with pieces on every row."""
+    from src.baseline.state import BitboardState
+    rows = []
+
+    def record(w, b, turn):
+        stt = BitboardState(white=w, black=b, turn=turn)
+        mv = sorted(stt.get_legal_moves())
+        assert len(mv) <= 48
+        win = stt.check_win()
+        rows.append(dict(white=w, black=b, turn=turn, k=len(mv),
+                         frm=[m[0] for m in mv] + [255] * (48 - len(mv)),
+                         to=[m[1] for m in mv] + [255] * (48 - len(mv)),
+                         terminal=int(stt.is_terminal()), win=0 if win is None else int(win)))
+
+    record(0xFFFF, 0xFFFF << 48, WHITE)
+    rng = random.Random(42)                    # tests/test_compatibility.py:49-78
+    for _ in range(20):
+        w = b = 0
+        for sq in range(64):
+            if sq // 8 in (0, 7):
+                continue
+            p = rng.random()
+            if p < 0.1:
+                w |= 1 << sq
+            elif p < 0.2:
+                b |= 1 << sq
+        for turn in (WHITE, BLACK):
+            record(w, b, turn)
+    rng = random.Random(909)                   # reachable positions, terminal ones included
+    while len(rows) < 441:
+        g = BreakthroughGame()
+        while True:
+            w, b = game_bits(g)
+            if rng.random() < 0.35:
+                record(w, b, g.turn)
+            if g.is_terminal():
+                break
+            g.step(rng.choice(g.get_legal_moves()))
+    rng = random.Random(4711)                  # arbitrary boards: any row, any density
+    for i in range(200):
+        dens = rng.choice((0.05, 0.15, 0.3, 0.45))
+        w = b = 0
+        for sq in range(64):
+            p = rng.random()
+            if p < dens:
+                w |= 1 << sq
+            elif p < 2 * dens:
+                b |= 1 << sq
+        record(w, b, WHITE if i % 2 == 0 else BLACK)
+    out = {"white": np.array([r["white"] for r in rows], np.uint64),
+           "black": np.array([r["black"] for r in rows], np.uint64),
+           "turn": np.array([r["turn"] for r in rows], np.int8),
+           "k": np.array([r["k"] for r in rows], np.uint8),
+           "frm": np.array([r["frm"] for r in rows], np.uint8),
+           "to": np.array([r["to"] for r in rows], np.uint8),
+           "terminal": np.array([r["terminal"] for r in rows], np.int8),
+           "win": np.array([r["win"] for r in rows], np.int8)}
+    np.savez_compressed(os.path.join(HERE, "baseline_movegen_tier.npz"), **out)
+    print("baseline movegen tier:", len(rows), "positions,", int(out["terminal"].sum()), "terminal")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     tiers = {"table": make_table, "game": make_game_tier, "tree": make_tree_tier,
              "tree_wide": make_tree_wide_tier, "tree_cpuct": make_tree_cpuct_tier, "tree_deep": make_tree_deep_tier, "probs": make_probs_tier,
-             "selfplay": make_selfplay_tier, "selfplay_wide": make_selfplay_wide_tier, "nn": make_nn_tier, "train": make_train_tier}
+             "selfplay": make_selfplay_tier, "selfplay_wide": make_selfplay_wide_tier, "nn": make_nn_tier, "train": make_train_tier,
+             "latency": make_latency_tier, "baseline_movegen": make_baseline_movegen_tier}
     for name in (sys.argv[1:] or list(tiers)):
         tiers[name]()

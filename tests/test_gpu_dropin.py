@@ -149,3 +149,48 @@ class TestReferenceSemantics:      # tests/test_mcts.py:48-195 with the real (bf
         mcts.search(g, root=child)
         with pytest.raises(AzError):
             sibling.children
+
+
+def _arena_move(root):
+    """src/arena.py:257-262 / src/web.py:455-460, verbatim in meaning: iterate root.children in
+    insertion order, keep the first strictly largest visit count."""
+    best_action, best_visits = -1, -1
+    for action, child in root.children.items():
+        if child.visit_count > best_visits:
+            best_visits, best_action = child.visit_count, action
+    return best_action
+
+
+def test_latency_search_picks_the_reference_moves(golden_dir):
+    """MCTS.search(game, add_noise=False) with a fresh root at 200 simulations, as Arena.play_game
+    and make_alphazero_move call it: root statistics, the move picked from them by insertion
+    order, and root.value() equal the reference's; the game object is not touched."""
+    d = np.load(os.path.join(golden_dir, "latency_tier.npz"))
+    m = _table_mcts(int(d["sims"]))
+    for g in range(len(d["white"])):
+        game = _game(d["white"][g], d["black"][g], d["turn"][g])
+        board0, turn0 = game.board.copy(), game.turn
+        root = m.search(game, add_noise=False)
+        assert np.array_equal(game.board, board0) and game.turn == turn0
+        _check_children(_stats(root), d, "fresh", g)
+        assert _arena_move(root) == int(d["best_action"][g])
+        assert float(root.value()) == float(d["root_value"][g])
+
+
+def test_arena_game_through_the_dropin_equals_the_reference_game(golden_dir):
+    """A whole Arena.play_game (src/arena.py:231-270) through the drop-in classes: same moves,
+    same visit counts behind them, same final position and result."""
+    from alphazero_amd.game import BreakthroughGame, board_to_bits
+    d = np.load(os.path.join(golden_dir, "latency_tier.npz"))
+    m = _table_mcts(int(d["sims"]))
+    game = BreakthroughGame()
+    for ply, want in enumerate(d["game_actions"]):
+        assert not game.is_terminal()
+        root = m.search(game, add_noise=False)
+        a = _arena_move(root)
+        assert a == int(want), ply
+        assert root.children[a].visit_count == int(d["game_best_visits"][ply])
+        game.step(game.decode_action(a))
+    assert game.is_terminal()
+    assert tuple(np.float32(x) for x in game.get_result()) == tuple(d["game_result"])
+    assert tuple(int(x) for x in board_to_bits(game.board)) == tuple(int(x) for x in d["game_final"])

@@ -91,3 +91,13 @@ def test_movegen_one_million_positions():
     for dd in range(3):
         pc += np.array([bin(int(x)).count("1") for x in legal3[:2000, dd]] + [0] * (n - 2000))
     assert np.array_equal(pc[:2000], mask[:2000].sum(axis=1))
+
+
+def test_movegen_matches_the_reference_baseline_engine(golden_dir):
+    """Second, independently written oracle: the move sets, is_terminal and check_win of the
+    reference's bitboard engine (src/baseline/state.py:90-311), which the reference's own
+    tests/test_compatibility.py cross-checks against src/game.py."""
+    from test_oracle_golden import check_against_baseline_engine
+    d = np.load(os.path.join(golden_dir, "baseline_movegen_tier.npz"))
+    legal3, _, _, status = _run(d["white"], d["black"], d["turn"], want_mask=False, want_planes=False)
+    check_against_baseline_engine(d, legal3, status)

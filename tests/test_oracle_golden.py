@@ -213,3 +213,83 @@ def test_tree_deep_reuse_bit_exact(golden_dir):
     d = np.load(os.path.join(golden_dir, "tree_deep_tier.npz"))
     checked, top = replay_deep_tier(orc.OracleMCTS(len(d["white"]), c_puct=1.5), d)
     assert checked == int((d["played"] != 255).sum()) and top > 1500
+
+
+# ---------------------------------------------------------------- arena / web latency search
+def best_by_visits(actions, visits):
+    """src/arena.py:257-262, src/web.py:455-460: first child in insertion order with the
+    strictly largest visit count."""
+    best_action, best_visits = -1, -1
+    for a, n in zip(actions, visits):
+        if int(n) > best_visits:
+            best_visits, best_action = int(n), int(a)
+    return best_action
+
+
+def test_latency_search_matches_reference(golden_dir):
+    """MCTS.search(game, add_noise=False) on a fresh root at 200 simulations (src/mcts.py:76-92
+    as arena.py and web.py call it), the move they pick from it and the value web.py shows."""
+    d = np.load(os.path.join(golden_dir, "latency_tier.npz"))
+    ev, S = TableEvaluator(), int(d["sims"])
+    for g in range(len(d["white"])):
+        m = orc.OracleMCTS(1)
+        m.set_game(0, orc.make_pos(d["white"][g], d["black"][g], d["turn"][g]))
+        m.search(ev, S)
+        st = m.root_children(0)
+        _check_children(st, d, "fresh", g)
+        assert best_by_visits(st["actions"], st["N"]) == int(d["best_action"][g])
+        assert float(np.float32(st["root_W"]) / np.float32(st["root_N"])) == float(d["root_value"][g])
+
+
+def test_arena_game_matches_reference(golden_dir):
+    """A whole Arena.play_game (src/arena.py:231-270): fresh root every move, most visited child."""
+    d = np.load(os.path.join(golden_dir, "latency_tier.npz"))
+    ev, S = TableEvaluator(), int(d["sims"])
+    pos = orc.start_position()
+    for ply, want in enumerate(d["game_actions"]):
+        assert not orc.is_terminal(pos)
+        m = orc.OracleMCTS(1)
+        m.set_game(0, pos)
+        m.search(ev, S)
+        st = m.root_children(0)
+        a = best_by_visits(st["actions"], st["N"])
+        assert a == int(want), ply
+        assert int(st["N"][list(st["actions"]).index(a)]) == int(d["game_best_visits"][ply])
+        pos = orc.step_action(pos, a)
+    assert orc.is_terminal(pos) and orc.get_result(pos) == tuple(float(x) for x in d["game_result"])
+    assert (pos.white, pos.black) == tuple(int(x) for x in d["game_final"])
+
+
+# ---------------------------------------------------------------- second movegen oracle
+def legal3_to_moves(legal3_row, turn):
+    """Per-direction canonical source masks -> {(from, to)} on the real board."""
+    out = set()
+    for d, step in enumerate((8, 7, 9)):
+        bits = int(legal3_row[d])
+        for sq in range(64):
+            if (bits >> sq) & 1:
+                to = sq + step
+                out.add((sq, to) if turn > 0 else (63 - sq, 63 - to))
+    return out
+
+
+def check_against_baseline_engine(d, legal3, status):
+    """legal3 / status of a move generator against src/baseline/state.py's answers."""
+    for i in range(len(d["white"])):
+        want = {(int(f), int(t)) for f, t in zip(d["frm"][i][: d["k"][i]], d["to"][i][: d["k"][i]])}
+        assert legal3_to_moves(legal3[i], int(d["turn"][i])) == want, i
+    w, b = d["white"].astype(np.uint64), d["black"].astype(np.uint64)
+    # BitboardState.is_terminal (state.py:276-288): a piece on its goal row or a side extinct
+    assert np.array_equal((status == 1) | (status == -1), d["terminal"].astype(bool))
+    # check_win (state.py:290-311) where only one side has a claim (arbitrary boards may have both)
+    white_claim = ((w & np.uint64(0xFF << 56)) != 0) | (b == 0)
+    black_claim = ((b & np.uint64(0xFF)) != 0) | (w == 0)
+    one = white_claim ^ black_claim
+    assert one.sum() > 50
+    assert np.array_equal(status[one], d["win"][one])
+
+
+def test_oracle_movegen_matches_the_baseline_engine(golden_dir):
+    d = np.load(os.path.join(golden_dir, "baseline_movegen_tier.npz"))
+    legal3, _, _, status = orc.movegen_batch(d["white"], d["black"], d["turn"], want_mask=False, want_planes=False)
+    check_against_baseline_engine(d, legal3, status)
