@@ -88,9 +88,13 @@ _SIGNATURES = {
     "az_engine_play_move": [_VP, C.c_int32, C.c_int32, _VP, C.c_int32, _VP],
     "az_engine_chosen_actions": [_VP, _VP, _VP],
     "az_engine_drain_samples": [_VP, C.c_int64, _VP, _VP, _VP, C.POINTER(C.c_int64), _VP],
+    "az_engine_drain_packed": [_VP, C.c_int64, _VP, C.POINTER(C.c_int64), _VP],
+    "az_unpack_samples": [C.c_int64, _VP, _VP, _VP, _VP, _VP],
     "az_engine_selfplay_stats": [_VP, C.POINTER(SelfplayStats), _VP],
 }
 _OPTIONAL = {}
+
+PACKED_SAMPLE_BYTES = 792     # AZ_PACKED_SAMPLE_BYTES
 
 _lib = None
 

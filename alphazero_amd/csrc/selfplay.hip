@@ -188,6 +188,35 @@ __global__ void k_unpack_samples(SelfplayView S, uint32_t n, float* states, floa
     if (lane < 2) wls[2 * (size_t)q + lane] = S.q_wl[2 * (size_t)q + lane];
 }
 
+// Wire format of one sample for the exchange between GPUs: 792 bytes =
+// mine u64 | theirs u64 | wl f32[2] | pi f32[192]  (half the 1544 bytes of the float planes).
+__global__ __launch_bounds__(64) void k_pack_samples(SelfplayView S, uint32_t n, uint8_t* packed) {
+    const uint32_t q = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (q >= n) return;
+    uint8_t* row = packed + (size_t)q * AZ_PACKED_SAMPLE_BYTES;
+    if (lane == 0) {
+        reinterpret_cast<uint64_t*>(row)[0] = S.q_mine[q];
+        reinterpret_cast<uint64_t*>(row)[1] = S.q_theirs[q];
+    }
+    float* f = reinterpret_cast<float*>(row + 16);
+    if (lane < 2) f[lane] = S.q_wl[2 * (size_t)q + lane];
+    for (int i = lane; i < 192; i += 64) f[2 + i] = S.q_pi[(size_t)q * 192 + i];
+}
+
+__global__ __launch_bounds__(64) void k_unpack_packed(const uint8_t* packed, uint32_t n, float* states, float* policies,
+                                                      float* wls) {
+    const uint32_t q = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (q >= n) return;
+    const uint8_t* row = packed + (size_t)q * AZ_PACKED_SAMPLE_BYTES;
+    const uint64_t mine = reinterpret_cast<const uint64_t*>(row)[0], theirs = reinterpret_cast<const uint64_t*>(row)[1];
+    write_planes(states + (size_t)q * 192, mine, theirs, lane);
+    const float* f = reinterpret_cast<const float*>(row + 16);
+    if (lane < 2) wls[2 * (size_t)q + lane] = f[lane];
+    for (int i = lane; i < 192; i += 64) policies[(size_t)q * 192 + i] = f[2 + i];
+}
+
 // One simulation's tree work for one game in ONE launch: finish the network heads for
 // the leaf (softmax / value), expand it, back the value up, then run the next
 // simulation's PUCT descent (src/mcts.py:153-187).
@@ -419,6 +448,37 @@ extern "C" int az_engine_drain_samples(az_engine* e, int64_t max_samples, float*
     AZ_HIP(hipGetLastError());
     AZ_HIP(hipMemsetAsync(e->sp.q_count, 0, sizeof(uint32_t), s));
     AZ_HIP(hipStreamSynchronize(s));
+    return AZ_OK;
+}
+
+extern "C" int az_engine_drain_packed(az_engine* e, int64_t max_samples, void* packed_dev, int64_t* n_out, void* stream) {
+    AZ_CHECK_ARG(e && n_out && e->sp_ready, "az_engine_drain_packed: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t n = 0;
+    AZ_HIP(hipMemcpyAsync(&n, e->sp.q_count, sizeof n, hipMemcpyDeviceToHost, s));
+    AZ_HIP(hipStreamSynchronize(s));
+    *n_out = n;
+    if (n == 0 || !packed_dev) return AZ_OK;
+    AZ_CHECK_ARG((int64_t)n <= max_samples, "az_engine_drain_packed: %u samples queued, room for %lld", n,
+                 (long long)max_samples);
+    AZ_CHECK_ARG(((uintptr_t)packed_dev & 7) == 0, "az_engine_drain_packed: the buffer must be 8-byte aligned");
+    hipLaunchKernelGGL(k_pack_samples, dim3(n), dim3(64), 0, s, e->sp, n, (uint8_t*)packed_dev);
+    AZ_HIP(hipGetLastError());
+    AZ_HIP(hipMemsetAsync(e->sp.q_count, 0, sizeof(uint32_t), s));
+    AZ_HIP(hipStreamSynchronize(s));
+    return AZ_OK;
+}
+
+extern "C" int az_unpack_samples(int64_t n, const void* packed_dev, float* states_dev, float* policies_dev,
+                                 float* wls_dev, void* stream) {
+    AZ_CHECK_ARG(n >= 0 && n < (1ll << 31), "az_unpack_samples: n = %lld out of range", (long long)n);
+    if (n == 0) return AZ_OK;
+    AZ_CHECK_ARG(packed_dev && states_dev && policies_dev && wls_dev, "az_unpack_samples: null pointer");
+    AZ_CHECK_ARG(((uintptr_t)packed_dev & 7) == 0 && ((uintptr_t)states_dev & 15) == 0,
+                 "az_unpack_samples: packed rows must be 8-byte aligned, states 16-byte aligned");
+    hipLaunchKernelGGL(k_unpack_packed, dim3((uint32_t)n), dim3(64), 0, (hipStream_t)stream, (const uint8_t*)packed_dev,
+                       (uint32_t)n, states_dev, policies_dev, wls_dev);
+    AZ_HIP(hipGetLastError());
     return AZ_OK;
 }
 

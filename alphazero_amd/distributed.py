@@ -46,11 +46,35 @@ def all_gather_samples(states: torch.Tensor, policies: torch.Tensor, wls: torch.
     return tuple(out)
 
 
-def allreduce_mean_gradients(model: torch.nn.Module, group=None, bucket_bytes: int = 32 << 20):
-    """Average .grad over ranks with flat buckets (the 20x128 network's 32 MB of
-    float32 gradients go out as one bucket by default)."""
+def all_gather_packed(packed: torch.Tensor, group=None) -> torch.Tensor:
+    """All-gather of ragged row blocks: every rank contributes packed[n_r, width] (n_r may
+    differ, may be 0) and receives all rows, in rank order.  One count exchange, then ONE
+    all_gather_into_tensor of the padded blocks.  Used with the engine's packed sample rows
+    (Engine.drain_packed: 792 bytes per sample instead of 1544); unpack the result on the
+    receiving GPU with engine.unpack_samples."""
     world = dist.get_world_size(group)
-    params = [p for p in model.parameters() if p.grad is not None]
+    width = packed.shape[1]
+    n = torch.tensor([packed.shape[0]], dtype=torch.int64, device=packed.device)
+    counts = torch.empty(world, dtype=torch.int64, device=packed.device)
+    dist.all_gather_into_tensor(counts, n, group=group)
+    counts = [int(c) for c in counts.tolist()]
+    cap = max(counts)
+    if cap == 0:
+        return packed[:0].clone()
+    pad = packed
+    if packed.shape[0] != cap:
+        pad = torch.zeros((cap, width), dtype=packed.dtype, device=packed.device)
+        pad[: packed.shape[0]] = packed
+    out = torch.empty((world * cap, width), dtype=packed.dtype, device=packed.device)
+    dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
+    if all(c == cap for c in counts):
+        return out
+    return torch.cat([out[r * cap: r * cap + c] for r, c in enumerate(counts)], dim=0)
+
+
+def _flat_allreduce(tensors: List[torch.Tensor], group=None, bucket_bytes: int = 32 << 20):
+    """In-place SUM all-reduce of a list of tensors through flat buckets (the 20x128
+    network's 32 MB of float32 gradients go out as one bucket by default)."""
     bucket: List[torch.Tensor] = []
     size = 0
 
@@ -58,22 +82,49 @@ def allreduce_mean_gradients(model: torch.nn.Module, group=None, bucket_bytes: i
         nonlocal bucket, size
         if not bucket:
             return
-        flat = torch.cat([p.grad.reshape(-1) for p in bucket])
+        flat = torch.cat([t.reshape(-1) for t in bucket])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        flat.div_(world)
         off = 0
-        for p in bucket:
-            k = p.grad.numel()
-            p.grad.copy_(flat[off: off + k].view_as(p.grad))
+        for t in bucket:
+            k = t.numel()
+            t.copy_(flat[off: off + k].view_as(t))
             off += k
         bucket, size = [], 0
 
-    for p in params:
-        bucket.append(p)
-        size += p.grad.numel() * p.grad.element_size()
+    for t in tensors:
+        bucket.append(t)
+        size += t.numel() * t.element_size()
         if size >= bucket_bytes:
             flush()
     flush()
+
+
+def allreduce_gradients(model: torch.nn.Module, weight: float, group=None, bucket_bytes: int = 32 << 20):
+    """Replace every .grad by the sum over ranks of weight_r * grad_r.  With
+    weight_r = (examples in rank r's slice) / (examples in the whole batch) that sum is the
+    gradient of the mean loss over the whole batch, however ragged the slices are (an equal
+    1/world would give a slice of one example the weight of a full one)."""
+    grads = [p.grad for p in model.parameters() if p.grad is not None]
+    if weight != 1.0:
+        for g in grads:
+            g.mul_(weight)
+    _flat_allreduce(grads, group, bucket_bytes)
+
+
+def sync_batchnorm_buffers(model: torch.nn.Module, weight: float, group=None):
+    """Keep the replicas' BatchNorm running statistics identical: each rank updated them from
+    its own slice, so they are replaced by the slice-size-weighted mean over the ranks (a
+    rank with an empty slice ran no forward and counts for nothing); num_batches_tracked
+    becomes the maximum.  Self-play folds these statistics into the convolution weights, so
+    without this every rank would play with a different network after one learn()."""
+    floats = [b for b in model.buffers() if b.is_floating_point()]
+    if floats:
+        for b in floats:
+            b.mul_(weight)
+        _flat_allreduce(floats, group)
+    for b in model.buffers():
+        if not b.is_floating_point():
+            dist.all_reduce(b, op=dist.ReduceOp.MAX, group=group)
 
 
 def losses(model, states, target_pis, target_wls):
@@ -85,12 +136,16 @@ def losses(model, states, target_pis, target_wls):
     return loss_pi + loss_wl, loss_pi, loss_wl
 
 
-def train_step(model, optimizer, states, target_pis, target_wls, group=None, autocast_dtype=None):
-    """One optimisation step on this rank's slice of the batch; gradients are
-    averaged over the ranks of `group` when torch.distributed is initialised.  A
-    rank whose slice is empty (ragged last batch) contributes zero gradients and
-    still joins the all-reduce.  autocast_dtype (e.g. torch.bfloat16) runs the
-    forward under torch.autocast; None is the reference's float32 step."""
+def train_step(model, optimizer, states, target_pis, target_wls, group=None, autocast_dtype=None,
+               global_batch=None):
+    """One optimisation step on this rank's slice of the batch.  With torch.distributed
+    initialised the ranks' gradients are combined with weights slice/global_batch (the
+    gradient of the whole batch's mean loss; global_batch = None: the slice sizes are
+    summed over the ranks first) and the BatchNorm running statistics are averaged the same
+    way, so the replicas - parameters and buffers - stay identical.  A rank whose slice is
+    empty (ragged last batch) contributes zero gradients and still joins the collectives.
+    autocast_dtype (e.g. torch.bfloat16) runs the forward under torch.autocast; None is the
+    reference's float32 step."""
     model.train()
     optimizer.zero_grad()
     if states.shape[0] > 0:
@@ -119,7 +174,15 @@ def train_step(model, optimizer, states, target_pis, target_wls, group=None, aut
             p.grad = torch.zeros_like(p)
         out = (0.0, 0.0, 0.0)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        allreduce_mean_gradients(model, group)
+        mine = states.shape[0]
+        if global_batch is None:
+            total = torch.tensor([mine], dtype=torch.int64, device=states.device)
+            dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+            global_batch = int(total.item())
+        weight = mine / max(1, global_batch)
+        allreduce_gradients(model, weight, group)
+        with torch.no_grad():
+            sync_batchnorm_buffers(model, weight, group)
     if Config.GRAD_CLIP_NORM > 0:
         torch.nn.utils.clip_grad_norm_(model.parameters(), Config.GRAD_CLIP_NORM)
     optimizer.step()

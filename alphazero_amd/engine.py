@@ -25,6 +25,22 @@ def _stream(device=None):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+def unpack_samples(packed):
+    """Packed sample rows (uint8 cuda tensor [n, 792], from any rank's Engine.drain_packed)
+    -> (states[n,3,8,8], policies[n,192], wls[n,2]) float32 cuda tensors."""
+    assert packed.is_cuda and packed.dtype == torch.uint8 and packed.is_contiguous()
+    assert packed.dim() == 2 and packed.shape[1] == _lib.PACKED_SAMPLE_BYTES
+    n, dev = packed.shape[0], packed.device
+    states = torch.empty((n, 3, 8, 8), dtype=torch.float32, device=dev)
+    policies = torch.empty((n, 192), dtype=torch.float32, device=dev)
+    wls = torch.empty((n, 2), dtype=torch.float32, device=dev)
+    if n:
+        with torch.cuda.device(dev):
+            check(_lib.lib().az_unpack_samples(n, _dev_ptr(packed), _dev_ptr(states), _dev_ptr(policies),
+                                               _dev_ptr(wls), _stream(dev)))
+    return states, policies, wls
+
+
 class Engine:
     """B games, one tree each, resident on one GPU."""
 
@@ -277,6 +293,18 @@ class Engine:
                                                      _dev_ptr(wls), C.byref(got), _stream(self.device)))
             assert got.value == n
         return states, policies, wls
+
+    def drain_packed(self):
+        """The queued samples in the wire format of the exchange between GPUs:
+        a uint8 cuda tensor [n, 792] (see unpack_samples); empties the queue."""
+        n = self.samples_pending()
+        packed = torch.empty((n, _lib.PACKED_SAMPLE_BYTES), dtype=torch.uint8, device=self.device)
+        if n:
+            got = C.c_int64()
+            with torch.cuda.device(self.device):
+                check(_lib.lib().az_engine_drain_packed(self.h, n, _dev_ptr(packed), C.byref(got), _stream(self.device)))
+            assert got.value == n
+        return packed
 
     def stats(self):
         st = _lib.SelfplayStats()

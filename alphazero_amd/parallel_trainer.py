@@ -51,6 +51,15 @@ def _mirror_permutation() -> np.ndarray:
 MIRROR_PERM = _mirror_permutation()
 
 
+def _concrete(device) -> torch.device:
+    """torch.device with the ordinal filled in ("cuda" -> "cuda:<current>"), so that it
+    compares equal to the device of tensors that live there."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
 def augment_example(state: np.ndarray, policy: np.ndarray, wl: np.ndarray) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """Left-right mirror of one example (src/parallel_trainer.py:33-70): planes
     flipped along the column axis, policy permuted, wl unchanged."""
@@ -60,16 +69,56 @@ def augment_example(state: np.ndarray, policy: np.ndarray, wl: np.ndarray) -> Tu
 class ExampleArrays:
     """n training examples as arrays states[n,3,8,8], policies[n,192], wls[n,2]
     (the layout of training_data.npz) that reads like the reference's list of
-    (state, policy, wl) tuples: len, indexing, slicing, iteration, +."""
+    (state, policy, wl) tuples: len, indexing, slicing, iteration, +.
 
-    __slots__ = ("states", "policies", "wls")
+    The three arrays may be given as numpy arrays or as torch tensors on any device.
+    Examples that were produced on a GPU stay there: `.states`, `.policies` and `.wls`
+    (numpy) are made on first use, `tensors(device)` hands out torch tensors without a
+    host round trip when they already live on that device."""
+
+    __slots__ = ("_np", "_t")
 
     def __init__(self, states=None, policies=None, wls=None):
-        self.states = np.zeros((0, 3, BOARD_SIZE, BOARD_SIZE), np.float32) if states is None else np.asarray(states, np.float32)
-        self.policies = np.zeros((0, NUM_ACTIONS), np.float32) if policies is None else np.asarray(policies, np.float32)
-        self.wls = np.zeros((0, 2), np.float32) if wls is None else np.asarray(wls, np.float32)
-        if not (len(self.states) == len(self.policies) == len(self.wls)):
+        if torch.is_tensor(states):
+            t = tuple(x.detach().to(torch.float32).contiguous() for x in (states, policies, wls))
+            if not (t[0].shape[0] == t[1].shape[0] == t[2].shape[0]):
+                raise ValueError("states, policies and wls must have the same length")
+            self._t = (t[0].reshape(-1, 3, BOARD_SIZE, BOARD_SIZE), t[1].reshape(-1, NUM_ACTIONS), t[2].reshape(-1, 2))
+            self._np = None
+            return
+        st = np.zeros((0, 3, BOARD_SIZE, BOARD_SIZE), np.float32) if states is None else np.asarray(states, np.float32)
+        po = np.zeros((0, NUM_ACTIONS), np.float32) if policies is None else np.asarray(policies, np.float32)
+        wl = np.zeros((0, 2), np.float32) if wls is None else np.asarray(wls, np.float32)
+        if not (len(st) == len(po) == len(wl)):
             raise ValueError("states, policies and wls must have the same length")
+        self._np = (st, po, wl)
+        self._t = None
+
+    def _host(self):
+        if self._np is None:
+            self._np = tuple(x.cpu().numpy() for x in self._t)
+        return self._np
+
+    @property
+    def states(self):
+        return self._host()[0]
+
+    @property
+    def policies(self):
+        return self._host()[1]
+
+    @property
+    def wls(self):
+        return self._host()[2]
+
+    def tensors(self, device):
+        """(states, policies, wls) as float32 torch tensors on `device`."""
+        device = _concrete(device)
+        if self._t is not None and self._t[0].device == device:
+            return self._t
+        if self._t is not None and self._np is None:
+            return tuple(x.to(device) for x in self._t)
+        return tuple(torch.from_numpy(np.ascontiguousarray(x)).to(device) for x in self._host())
 
     @classmethod
     def of(cls, examples) -> "ExampleArrays":
@@ -82,10 +131,12 @@ class ExampleArrays:
                    np.stack([e[2] for e in examples]))
 
     def __len__(self):
-        return len(self.states)
+        return len(self._np[0]) if self._np is not None else int(self._t[0].shape[0])
 
     def __getitem__(self, i):
         if isinstance(i, slice):
+            if self._np is None:
+                return ExampleArrays(self._t[0][i], self._t[1][i], self._t[2][i])
             return ExampleArrays(self.states[i], self.policies[i], self.wls[i])
         return self.states[i], self.policies[i], self.wls[i]
 
@@ -98,7 +149,7 @@ class ExampleArrays:
 
     def extend(self, other):
         merged = self + other
-        self.states, self.policies, self.wls = merged.states, merged.policies, merged.wls
+        self._np, self._t = merged._np, merged._t
 
     @staticmethod
     def concat(parts: Iterable["ExampleArrays"]) -> "ExampleArrays":
@@ -107,8 +158,87 @@ class ExampleArrays:
             return ExampleArrays()
         if len(parts) == 1:
             return parts[0]
+        devs = {p._t[0].device for p in parts if p._t is not None and p._np is None}
+        if len(devs) == 1 and all(p._t is not None for p in parts):
+            dev = devs.pop()
+            ts = [p.tensors(dev) for p in parts]
+            return ExampleArrays(*(torch.cat([t[i] for t in ts]) for i in range(3)))
         return ExampleArrays(np.concatenate([p.states for p in parts]), np.concatenate([p.policies for p in parts]),
                              np.concatenate([p.wls for p in parts]))
+
+
+class ReplayRing:
+    """The replay buffer (src/parallel_trainer.py:437-442: append, keep the most recent
+    `limit` examples) as a ring of rows in three tensors that live on the training device.
+    New examples are written behind the newest row and overwrite the oldest once `limit`
+    rows are held; nothing is moved or re-uploaded when the buffer is full.  Logical row i
+    (0 = oldest) is physical row (start + i) mod rows."""
+
+    def __init__(self, device):
+        self.device = _concrete(device)
+        self.s = self.p = self.w = None
+        self.rows = 0          # allocated rows
+        self.start = 0
+        self.n = 0
+        self.version = 0       # bumped by every change of the contents
+
+    def __len__(self):
+        return self.n
+
+    def clear(self):
+        self.s = self.p = self.w = None
+        self.rows = self.start = self.n = 0
+        self.version += 1
+
+    def physical(self, logical):
+        """Storage rows of logical rows (a tensor of indices on the ring's device)."""
+        return (logical + self.start) % self.rows if self.start else logical
+
+    def ordered(self) -> ExampleArrays:
+        """The contents, oldest first (views of the storage when it has not wrapped)."""
+        if self.n == 0:
+            return ExampleArrays()
+        if self.start == 0:
+            return ExampleArrays(self.s[:self.n], self.p[:self.n], self.w[:self.n])
+        idx = self.physical(torch.arange(self.n, device=self.device))
+        return ExampleArrays(self.s[idx], self.p[idx], self.w[idx])
+
+    def _rebuild(self, rows):
+        """Storage of `rows` rows holding the newest min(n, rows) examples from row 0 on."""
+        old = self.ordered() if self.n else None
+        keep = min(self.n, rows)
+        self.s = torch.empty((rows, 3, BOARD_SIZE, BOARD_SIZE), dtype=torch.float32, device=self.device)
+        self.p = torch.empty((rows, NUM_ACTIONS), dtype=torch.float32, device=self.device)
+        self.w = torch.empty((rows, 2), dtype=torch.float32, device=self.device)
+        if keep:
+            os_, op, ow = old.tensors(self.device)
+            self.s[:keep], self.p[:keep], self.w[:keep] = os_[self.n - keep:], op[self.n - keep:], ow[self.n - keep:]
+        self.rows, self.start, self.n = rows, 0, keep
+
+    def append(self, examples: ExampleArrays, limit: int):
+        limit = max(1, int(limit))
+        k = len(examples)
+        ts = examples.tensors(self.device) if k else None
+        if k > limit:
+            ts = tuple(t[k - limit:] for t in ts)
+            k = limit
+        if self.rows > limit:                        # the cap was lowered
+            self._rebuild(limit)
+        need = min(limit, self.n + k)
+        if need > self.rows:                         # grow (doubling) until the cap is reached
+            self._rebuild(min(limit, max(need, 2 * self.rows, 1024)))
+        if self.n > limit:                           # cap lowered below the contents without new rows
+            self.start = (self.start + self.n - limit) % self.rows
+            self.n = limit
+        if k:
+            pos = (torch.arange(k, device=self.device) + (self.start + self.n)) % self.rows
+            self.s.index_copy_(0, pos, ts[0])
+            self.p.index_copy_(0, pos, ts[1])
+            self.w.index_copy_(0, pos, ts[2])
+            over = max(0, self.n + k - min(limit, self.rows))
+            self.start = (self.start + over) % self.rows
+            self.n = self.n + k - over
+        self.version += 1
 
 
 class GameDataset(Dataset):
@@ -130,12 +260,15 @@ class GameDataset(Dataset):
         return tuple(torch.tensor(np.ascontiguousarray(x), dtype=torch.float32) for x in item)
 
 
-def gather_batch(states, policies, wls, idx, mirror_perm):
+def gather_batch(states, policies, wls, idx, mirror_perm, n=None, physical=None):
     """Rows idx of the augmented data set [examples ; mirrored examples] from
-    device-resident arrays; idx >= n addresses the mirrored copy of idx - n."""
-    n = states.shape[0]
+    device-resident arrays; idx >= n addresses the mirrored copy of idx - n.
+    `physical` maps example numbers to storage rows (a ReplayRing that has wrapped)."""
+    n = states.shape[0] if n is None else n
     mirrored = idx >= n
     real = torch.where(mirrored, idx - n, idx)
+    if physical is not None:
+        real = physical(real)
     s, p, w = states[real], policies[real], wls[real]
     s = torch.where(mirrored[:, None, None, None], s.flip(3), s)
     p = torch.where(mirrored[:, None], p[:, mirror_perm], p)
@@ -162,31 +295,49 @@ class ParallelTrainer:
         self.scheduler = CosineAnnealingLR(self.optimizer, T_max=Config.LR_SCHEDULER_T_MAX,
                                            eta_min=Config.LR_SCHEDULER_ETA_MIN)
         self.mcts = MCTS(model, num_simulations=num_simulations, device=device)
-        self._examples = ExampleArrays()
+        self._replay = ReplayRing(device)       # lives on the training device
+        self._examples_view = (None, -1)        # (ExampleArrays, ring version) of the last `examples` read
         self.max_examples = Config.BUFFER_SIZE
         self.checkpoint_dir = checkpoint_dir
         self.seed = seed
         self.verbose = verbose
         self.autocast_dtype = autocast_dtype   # None: the reference's float32 step; torch.bfloat16: autocast forward
         self._selfplay = None          # fused device self-play, built on first use
-        self._weights_changed = False  # the HIP inference copy is stale
+        self._selfplay_key = None      # version counters of the weights its HIP copy was made from
         os.makedirs(self.checkpoint_dir, exist_ok=True)
 
     # ------------------------------------------------------------------ replay buffer
     @property
     def examples(self) -> ExampleArrays:
-        return self._examples
+        """The replay buffer, oldest example first.  The rows live on the training device;
+        the numpy arrays behind this view are made when they are first read."""
+        view, version = self._examples_view
+        if version != self._replay.version:
+            view = self._replay.ordered()
+            self._examples_view = (view, self._replay.version)
+        return view
 
     @examples.setter
     def examples(self, value):
-        self._examples = ExampleArrays.of(value)
+        self._replay.clear()
+        self._replay.append(ExampleArrays.of(value), self.max_examples)
 
     def add_examples(self, new_examples):
-        """Append and keep the most recent `max_examples` (src/parallel_trainer.py:437-442)."""
-        merged = self._examples + new_examples
-        if len(merged) > self.max_examples:
-            merged = merged[len(merged) - self.max_examples:]
-        self._examples = merged
+        """Append and keep the most recent `max_examples` (src/parallel_trainer.py:437-442).
+        Examples that are already on the training device (what execute_parallel_episodes
+        returns on the fused path) are copied there, not through the host."""
+        self._replay.append(ExampleArrays.of(new_examples), self.max_examples)
+
+    def _weights_key(self):
+        m = self.model
+        return tuple(t._version for t in list(m.parameters()) + list(m.buffers()))
+
+    @property
+    def _weights_changed(self) -> bool:
+        """The fused self-play's bf16 copy of the weights is older than the module's tensors
+        (every in-place update - an optimiser step, load_state_dict, a caller's own change -
+        moves a tensor's version counter)."""
+        return self._selfplay is not None and self._selfplay_key != self._weights_key()
 
     def _say(self, msg):
         if self.verbose:
@@ -216,13 +367,13 @@ class ParallelTrainer:
                                                num_simulations=self.mcts.num_simulations,
                                                c_puct=self.mcts.c_puct, seed=self.seed,
                                                device=torch.device(self.device).index)
-                self._weights_changed = False
+                self._selfplay_key = self._weights_key()
             if self._weights_changed:
                 sp.inference.refresh()
-                self._weights_changed = False
+                self._selfplay_key = self._weights_key()
             if continuous:
-                return ExampleArrays(*sp.collect_games(num_games))
-            return ExampleArrays(*sp.execute_parallel_episodes(num_games))
+                return ExampleArrays(*sp.collect_games(num_games, device_output=True))
+            return ExampleArrays(*sp.execute_parallel_episodes(num_games, device_output=True))
         if continuous:
             raise RuntimeError("continuous self-play runs on the fused engine only (a HIP-supported AlphaZeroNet on a GPU)")
         return self._host_loop_episodes(num_games)
@@ -271,13 +422,12 @@ class ParallelTrainer:
         averaged.  Returns the mean losses of the last epoch."""
         from . import distributed as azdist
         import torch.distributed as dist
-        n = len(self._examples)
+        ring = self._replay
+        n = len(ring)
         if n == 0:
             return None
-        dev = torch.device(self.device)
-        states = torch.from_numpy(self._examples.states).to(dev)
-        policies = torch.from_numpy(self._examples.policies).to(dev)
-        wls = torch.from_numpy(self._examples.wls).to(dev)
+        dev = ring.device
+        states, policies, wls = ring.s, ring.p, ring.w     # gathered in place: no copy of the buffer
         perm = torch.from_numpy(MIRROR_PERM).to(dev)
         # same sampler, same draws from the global torch RNG as a DataLoader over the 2n examples
         index_batches = DataLoader(torch.arange(2 * n), batch_size=batch_size, shuffle=True)
@@ -290,14 +440,15 @@ class ParallelTrainer:
             tot = np.zeros(3)
             count = 0
             for idx in index_batches:
+                global_batch = len(idx)
                 if world > 1:
                     idx = idx[rank::world]
-                s, p, w = gather_batch(states, policies, wls, idx.to(dev), perm)
-                tot += azdist.train_step(self.model, self.optimizer, s, p, w, autocast_dtype=self.autocast_dtype)
+                s, p, w = gather_batch(states, policies, wls, idx.to(dev), perm, n=n, physical=ring.physical)
+                tot += azdist.train_step(self.model, self.optimizer, s, p, w, autocast_dtype=self.autocast_dtype,
+                                         global_batch=global_batch)
                 count += 1
             stats = dict(zip(("loss", "pi", "wl"), (tot / max(count, 1)).tolist()))
         self.scheduler.step()
-        self._weights_changed = True
         return stats
 
     # ------------------------------------------------------------------ checkpoints
@@ -317,7 +468,6 @@ class ParallelTrainer:
         if "scheduler" in ck:
             self.scheduler.load_state_dict(ck["scheduler"])
             self.scheduler.T_max = Config.LR_SCHEDULER_T_MAX   # the code's horizon wins over the file's
-        self._weights_changed = True
 
     def save_iteration_checkpoint(self, iteration: int):
         """iteration_N.pt with keys state_dict / optimizer / scheduler / iteration / config
@@ -386,11 +536,13 @@ class ParallelTrainer:
         path = self._get_data_file_path()
         if not os.path.exists(path):
             self._say("No training data file found")
-            self._examples = ExampleArrays()
+            self._replay.clear()
             return 0
         with np.load(path) as data:
             total = len(data["states"])
             start = max(0, total - max_examples)
-            self._examples = ExampleArrays(data["states"][start:], data["policies"][start:], data["wls"][start:])
-        self._say(f"Loaded {len(self._examples)} training examples (of {total} total on disk)")
-        return len(self._examples)
+            self._replay.clear()
+            self._replay.append(ExampleArrays(data["states"][start:], data["policies"][start:], data["wls"][start:]),
+                                max_examples)
+        self._say(f"Loaded {len(self._replay)} training examples (of {total} total on disk)")
+        return len(self._replay)

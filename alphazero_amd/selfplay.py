@@ -24,10 +24,17 @@ class SelfPlay:
         self.engine.attach_net(self.inference)
         self.engine.reset_all()
 
-    def execute_parallel_episodes(self, num_games=None):
+    @staticmethod
+    def _collected(out, device_output):
+        parts = tuple(torch.cat(o) for o in out)
+        return parts if device_output else tuple(t.cpu().numpy() for t in parts)
+
+    def execute_parallel_episodes(self, num_games=None, device_output=False):
         """Play every game to the end (finished games leave the batch, as in the
         reference) and return the examples as float32 arrays
-        (states[n,3,8,8], policies[n,192], wls[n,2])."""
+        (states[n,3,8,8], policies[n,192], wls[n,2]): numpy arrays, or with
+        device_output=True the cuda tensors the engine drained its queue into (no
+        host copy; what a trainer on the same GPU wants)."""
         e = self.engine
         n = e.n if num_games is None else int(num_games)
         assert n <= e.n
@@ -41,13 +48,13 @@ class SelfPlay:
             e.play_move(self.num_simulations, add_noise=True, restart_finished=False)
             if e.samples_pending() > e.n * 64:
                 for o, t in zip(out, e.drain_samples()):
-                    o.append(t.cpu())
+                    o.append(t)
         for o, t in zip(out, e.drain_samples()):
-            o.append(t.cpu())
+            o.append(t)
         self._finished0 = e.stats()["games_finished"]
-        return tuple(torch.cat(o).numpy() for o in out)
+        return self._collected(out, device_output)
 
-    def collect_games(self, num_games=None):
+    def collect_games(self, num_games=None, device_output=False):
         """Continuous self-play: every slot of the engine stays busy (a finished game restarts
         from the start position at once) until num_games more games have finished; returns
         their examples like execute_parallel_episodes.  Games still running when the call
@@ -66,11 +73,11 @@ class SelfPlay:
             e.play_move(self.num_simulations, add_noise=True, restart_finished=True)
             if e.samples_pending() > e.n * 64:
                 for o, t in zip(out, e.drain_samples()):
-                    o.append(t.cpu())
+                    o.append(t)
         for o, t in zip(out, e.drain_samples()):
-            o.append(t.cpu())
+            o.append(t)
         self._finished0 = e.stats()["games_finished"]
-        return tuple(torch.cat(o).numpy() for o in out)
+        return self._collected(out, device_output)
 
     def step(self, restart_finished=True):
         """One ply for every active game (continuous self-play when finished games restart)."""

@@ -446,17 +446,34 @@ def exchange_block(args, dist, model, rank, world, coll_dev, backend, barrier):
     with a gradient all-reduce (RCCL when backend is nccl)."""
     from alphazero_amd.model import AlphaZeroNet
     try:
-        from alphazero_amd.distributed import all_gather_samples, train_step
+        from alphazero_amd.distributed import all_gather_packed, train_step
+        from alphazero_amd._lib import PACKED_SAMPLE_BYTES
         n_s = args.games * 64
         g = torch.Generator(device=coll_dev).manual_seed(rank)
-        s_states = (torch.rand((n_s, 3, 8, 8), device=coll_dev, generator=g) > 0.7).float()
-        s_pis = torch.softmax(torch.rand((n_s, 192), device=coll_dev, generator=g), 1)
-        s_wls = torch.tensor([[1.0, 0.0]], device=coll_dev).repeat(n_s, 1)
+        # packed rows as the engine queues them (bitboards | wl | pi); the contents do not matter here
+        packed = torch.zeros((n_s, PACKED_SAMPLE_BYTES), dtype=torch.uint8, device=coll_dev)
+        fl = packed[:, 16:].view(torch.float32)
+        fl[:, 0] = 1.0
+        fl[:, 2:] = torch.softmax(torch.rand((n_s, 192), device=coll_dev, generator=g), 1)
+        packed[:, :16] = torch.randint(0, 2, (n_s, 16), device=coll_dev, generator=g, dtype=torch.uint8)
+        all_gather_packed(packed[:16])                # warm-up (RCCL channels)
         barrier()
         t1 = time.perf_counter()
-        G = all_gather_samples(s_states, s_pis, s_wls)
+        gathered = all_gather_packed(packed)
         barrier()
         t_gather = time.perf_counter() - t1
+        if gathered.is_cuda:
+            from alphazero_amd.engine import unpack_samples
+            t1 = time.perf_counter()
+            G = unpack_samples(gathered)
+            torch.cuda.synchronize()
+            t_unpack = time.perf_counter() - t1
+        else:                                         # gloo rehearsal: the unpack kernel needs the rows on a GPU
+            fl = gathered[:, 16:].view(torch.float32)
+            G = (torch.zeros((len(gathered), 3, 8, 8)), fl[:, 2:].clone(), fl[:, :2].clone())
+            G[0][:, 2] = 1.0
+            t_unpack = None
+        del gathered
         train_model = AlphaZeroNet(num_blocks=args.blocks, num_filters=128).to(coll_dev)
         train_model.load_state_dict(model.state_dict())
         opt = torch.optim.Adam(train_model.parameters(), lr=1e-3, weight_decay=1e-4)
@@ -473,7 +490,9 @@ def exchange_block(args, dist, model, rank, world, coll_dev, backend, barrier):
         tt = torch.tensor([t_gather, t_train], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return {"sample_allgather_ms": float(tt[0]) * 1e3, "samples_per_rank": n_s,
-                "bytes_per_rank": n_s * 1544, "train_step_ms": float(tt[1]) * 1e3,
+                "bytes_per_rank": n_s * PACKED_SAMPLE_BYTES, "wire_format": "packed rows of 792 B (bitboards | wl | pi f32)",
+                "unpack_ms": None if t_unpack is None else t_unpack * 1e3,
+                "train_step_ms": float(tt[1]) * 1e3,
                 "train_global_batch": per * world, "backend": backend}
     except Exception as exc:  # the self-play line must still be printed
         return {"error": repr(exc)}

@@ -262,6 +262,17 @@ int az_engine_chosen_actions(az_engine* e, int16_t* actions_host, void* stream);
  * states_dev == NULL only the count is reported. */
 int az_engine_drain_samples(az_engine* e, int64_t max_samples, float* states_dev,
                             float* policies_dev, float* wls_dev, int64_t* n_out, void* stream);
+/* The same queue in the wire format of the exchange between GPUs (no counterpart in the
+ * reference, which is one process: its src/parallel_trainer.py:201-213 appends to a Python
+ * list): rows of AZ_PACKED_SAMPLE_BYTES = canonical bitboards mine u64 | theirs u64 |
+ * wl f32[2] | pi f32[192], about half the size of the float planes.  packed_dev has room
+ * for max_samples rows and is 8-byte aligned; with packed_dev == NULL only the count is
+ * reported.  az_unpack_samples expands n such rows (from any rank) into the layout of
+ * az_engine_drain_samples; it needs no engine. */
+#define AZ_PACKED_SAMPLE_BYTES 792
+int az_engine_drain_packed(az_engine* e, int64_t max_samples, void* packed_dev, int64_t* n_out, void* stream);
+int az_unpack_samples(int64_t n, const void* packed_dev, float* states_dev, float* policies_dev,
+                      float* wls_dev, void* stream);
 int az_engine_selfplay_stats(az_engine* e, az_selfplay_stats* out, void* stream);
 
 #ifdef __cplusplus

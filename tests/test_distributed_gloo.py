@@ -41,6 +41,18 @@ def _worker(rank, world, port, ret):
         E = all_gather_samples(states[:0], policies[:0], wls[:0]) if rank == 1 else \
             all_gather_samples(states, policies, wls)
         assert E[0].shape[0] == 3                      # rank 1 sent nothing this time
+        # the packed form: ragged blocks of 792-byte rows, one all_gather_into_tensor, rank order kept
+        from alphazero_amd.distributed import all_gather_packed
+        rows = torch.full((4 - 3 * rank, 792), 17 + rank, dtype=torch.uint8)       # 4 rows from rank 0, 1 from rank 1
+        rows[:, 0] = torch.arange(len(rows), dtype=torch.uint8)
+        G = all_gather_packed(rows)
+        assert G.shape == (5, 792) and G.dtype == torch.uint8
+        assert G[:4, 1].eq(17).all() and G[4, 1] == 18 and G[:, 0].tolist() == [0, 1, 2, 3, 0]
+        G = all_gather_packed(rows[:0] if rank == 0 else rows)                      # rank 0 sends nothing
+        assert G.shape == (1, 792) and G[0, 1] == 18
+        assert all_gather_packed(rows[:0]).shape == (0, 792)                        # nobody sends anything
+        same = all_gather_packed(torch.full((3, 792), rank, dtype=torch.uint8))     # equal counts: no compaction
+        assert same.shape == (6, 792) and same[:3].eq(0).all() and same[3:].eq(1).all()
         # data-parallel step == single-process step on the concatenated batch (no BatchNorm
         # difference here: compare gradients computed in eval-mode statistics)
         torch.manual_seed(0)
@@ -56,21 +68,56 @@ def _worker(rank, world, port, ret):
         loss, _, _ = losses(model, X[lo:hi], PI[lo:hi], WL[lo:hi])
         model.zero_grad()
         loss.backward()
-        from alphazero_amd.distributed import allreduce_mean_gradients
-        allreduce_mean_gradients(model, bucket_bytes=4096)     # several buckets
+        from alphazero_amd.distributed import allreduce_gradients
+        allreduce_gradients(model, (hi - lo) / 8, bucket_bytes=4096)     # several buckets
         ref.eval()
         rl, _, _ = losses(ref, X, PI, WL)
         ref.zero_grad()
         rl.backward()
         for (k, p), q in zip(model.named_parameters(), ref.parameters()):
             assert torch.allclose(p.grad, q.grad, atol=1e-5), k
-        # the full step keeps the replicas identical
+        # ragged slices (6 + 2): the combined gradient is still the gradient of the mean loss
+        # over all 8 examples, not the mean of the two slice means
+        cut = 6
+        mine = slice(0, cut) if rank == 0 else slice(cut, 8)
+        loss, _, _ = losses(model, X[mine], PI[mine], WL[mine])
+        model.zero_grad()
+        loss.backward()
+        allreduce_gradients(model, (cut if rank == 0 else 8 - cut) / 8)
+        for (k, p), q in zip(model.named_parameters(), ref.parameters()):
+            assert torch.allclose(p.grad, q.grad, atol=1e-5), k
+        # the full step keeps the replicas identical: parameters AND BatchNorm buffers
         opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
-        train_step(model, opt, X[lo:hi], PI[lo:hi], WL[lo:hi])
-        flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
-        both = [torch.empty_like(flat) for _ in range(world)]
-        dist.all_gather(both, flat)
-        assert torch.equal(both[0], both[1])
+        train_step(model, opt, X[mine], PI[mine], WL[mine])          # global batch found by a count exchange
+        train_step(model, opt, X[lo:hi], PI[lo:hi], WL[lo:hi], global_batch=8)
+
+        def replicas_equal(m):
+            for k, v in m.state_dict().items():
+                both = [torch.empty_like(v) for _ in range(world)]
+                dist.all_gather(both, v.contiguous())
+                assert torch.equal(both[0], both[1]), k
+        replicas_equal(model)
+        assert float(model.input_bn.running_mean.abs().sum()) > 0    # the statistics did move
+        # a rank with an empty slice: the step equals a single-process step on the other rank's data
+        torch.manual_seed(3)
+        a, b = AlphaZeroNet(num_blocks=1, num_filters=16), AlphaZeroNet(num_blocks=1, num_filters=16)
+        b.load_state_dict(a.state_dict())
+        oa = torch.optim.Adam(a.parameters(), lr=1e-3, weight_decay=1e-4)
+        ob = torch.optim.Adam(b.parameters(), lr=1e-3, weight_decay=1e-4)
+        sl = slice(0, 5) if rank == 0 else slice(0, 0)
+        train_step(a, oa, X[sl], PI[sl], WL[sl], global_batch=5)
+        dist.barrier()
+        # single-process reference step: the same function with the collectives switched off
+        import alphazero_amd.distributed as azd
+        initialised = azd.dist.is_initialized
+        azd.dist.is_initialized = lambda: False
+        try:
+            train_step(b, ob, X[0:5], PI[0:5], WL[0:5])
+        finally:
+            azd.dist.is_initialized = initialised
+        for (k, v), u in zip(a.state_dict().items(), b.state_dict().values()):
+            assert torch.allclose(v.float(), u.float(), atol=1e-6), k
+        replicas_equal(a)
         ret[rank] = 1
     finally:
         dist.destroy_process_group()
@@ -104,6 +151,10 @@ def _learn_worker(rank, world, port, ret, tmp):
         both = [torch.empty_like(flat) for _ in range(world)]
         dist.all_gather(both, flat)
         assert torch.equal(both[0], both[1])              # replicas stay identical
+        for k, v in model.state_dict().items():           # ... buffers (BatchNorm statistics) included
+            both = [torch.empty_like(v) for _ in range(world)]
+            dist.all_gather(both, v.contiguous())
+            assert torch.equal(both[0], both[1]), k
         ret[rank] = 1
     finally:
         dist.destroy_process_group()

@@ -328,3 +328,32 @@ def test_bench_starts_its_own_ranks_on_the_gpu():
     # two ranks x 32 games x 16 simulations x 2 plies
     assert round(out["value"] * out["ms_per_step"] * 1e-3 * 2) == 2 * 32 * 16 * 2
     assert "error" not in out["exchange"] and out["exchange"]["backend"] == "gloo"
+
+
+def test_packed_samples_unpack_to_the_drained_arrays(small_model):
+    """Engine.drain_packed + unpack_samples (the wire format of the exchange between GPUs) give
+    exactly what az_engine_drain_samples gives: two engines with one seed play the same games."""
+    from alphazero_amd import _lib
+    from alphazero_amd.engine import unpack_samples
+    from alphazero_amd.selfplay import SelfPlay
+
+    def play():
+        sp = SelfPlay(small_model, n_games=24, num_simulations=12, seed=21, pool_nodes_per_game=1 << 14)
+        for _ in range(90):
+            sp.step(restart_finished=True)
+        return sp.engine
+    a, b = play(), play()
+    n = a.samples_pending()
+    assert n == b.samples_pending() and n > 200
+    want = [t.cpu().numpy() for t in a.drain_samples()]
+    packed = b.drain_packed()
+    assert packed.shape == (n, _lib.PACKED_SAMPLE_BYTES) and b.samples_pending() == 0
+    got = [t.cpu().numpy() for t in unpack_samples(packed)]
+    for g, w in zip(got, want):
+        assert np.array_equal(g.view(np.uint32), w.view(np.uint32))
+    # rows are self-contained: any subset, in any order, unpacks to the same rows
+    pick = torch.tensor([n - 1, 0, n // 2], device=packed.device)
+    sub = [t.cpu().numpy() for t in unpack_samples(packed[pick].contiguous())]
+    for g, w in zip(sub, want):
+        assert np.array_equal(g, w[pick.cpu().numpy()])
+    assert unpack_samples(packed[:0])[0].shape == (0, 3, 8, 8)

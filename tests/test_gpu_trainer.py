@@ -108,3 +108,66 @@ def test_continuous_collection_keeps_every_slot_busy(tmp_path):
     # the episodic mode afterwards starts clean
     third = tr.execute_parallel_episodes(4)
     assert len(third) >= 4 * 10
+
+
+def test_learn_on_the_gpu_reproduces_the_reference_weights(tmp_path):
+    """The reference trainer's learn(epochs=2, batch_size=16) on 48 synthetic examples from fixed
+    seeds (tests/golden/train_tier.npz, recorded on CPU) against the drop-in's learn() on
+    cuda: same shuffle (the DataLoader draws from the CPU generator), same batches, same
+    losses; the arithmetic is MIOpen/rocBLAS float32 instead of the CPU's.
+    Stated tolerance: every weight of the two stored tensors within 2e-4, per-tensor sums
+    within 2e-4 of the tensor's absolute sum + 1e-4 (measured on MI355X: 1.7e-5, 8e-8 and
+    1e-6; the slack is for Adam, whose first steps divide a gradient by its own magnitude
+    and so amplify float32 noise on elements whose gradient is close to zero)."""
+    from test_trainer_dropin import GOLD, train_examples
+    from alphazero_amd.model import AlphaZeroNet
+    from alphazero_amd.parallel_trainer import ParallelTrainer
+    torch.manual_seed(123)
+    model = AlphaZeroNet(num_blocks=1, num_filters=8).cuda()
+    tr = ParallelTrainer(model, device="cuda", num_parallel_games=2, num_simulations=4,
+                         checkpoint_dir=str(tmp_path), verbose=False)
+    tr.add_examples(train_examples())
+    assert tr._replay.s.is_cuda                                     # the buffer lives on the training device
+    torch.manual_seed(7)
+    stats = tr.learn(epochs=2, batch_size=16)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    assert list(sd.keys()) == [str(k) for k in GOLD["learn_keys"]]
+    sums = np.array([float(v.double().sum()) for v in sd.values()])
+    abs_sums = np.array([float(v.double().abs().sum()) for v in sd.values()])
+    err_conv = np.abs(sd["input_conv.weight"].numpy() - GOLD["learn_input_conv"]).max()
+    err_fc = np.abs(sd["value_fc2.weight"].numpy() - GOLD["learn_value_fc2"]).max()
+    err_sums = np.abs(sums - GOLD["learn_sums"]) / (GOLD["learn_abs_sums"] + 0.5)
+    print(f"gpu learn vs reference: input_conv max-abs {err_conv:.2e}, value_fc2 max-abs {err_fc:.2e}, "
+          f"worst per-tensor sum error relative to its absolute sum {err_sums.max():.2e}")
+    assert err_conv <= 2e-4 and err_fc <= 2e-4
+    assert np.all(np.abs(sums - GOLD["learn_sums"]) <= 2e-4 * GOLD["learn_abs_sums"] + 1e-4)
+    np.testing.assert_allclose(abs_sums, GOLD["learn_abs_sums"], rtol=2e-4, atol=1e-4)
+    assert tr.optimizer.param_groups[0]["lr"] == pytest.approx(float(GOLD["learn_lr_after"]), rel=1e-12)
+    assert np.isfinite(stats["loss"])
+
+
+def test_examples_stay_on_the_device_from_the_queue_to_the_optimiser(tmp_path, monkeypatch):
+    """execute_parallel_episodes -> add_examples -> learn on the fused path: the examples are
+    cuda tensors all the way; the numpy view of the buffer is only made when somebody reads it."""
+    from alphazero_amd.model import AlphaZeroNet
+    from alphazero_amd.parallel_trainer import ExampleArrays, ParallelTrainer
+    torch.manual_seed(4)
+    model = AlphaZeroNet(num_blocks=1, num_filters=128).cuda()
+    tr = ParallelTrainer(model, device="cuda", num_parallel_games=8, num_simulations=8,
+                         checkpoint_dir=str(tmp_path), seed=9, verbose=False)
+    ex = tr.execute_parallel_episodes()
+    assert ex._np is None and ex._t[0].is_cuda                      # nothing came to the host
+    tr.add_examples(ex)
+    assert tr._replay.s.is_cuda and len(tr._replay) == len(ex)
+    calls = []
+    monkeypatch.setattr(ExampleArrays, "_host", lambda self: calls.append(1) or (_ for _ in ()).throw(AssertionError("host copy")))
+    stats = tr.learn(epochs=1, batch_size=32)                       # gathers from the ring on the device
+    assert np.isfinite(stats["loss"]) and not calls
+    monkeypatch.undo()
+    assert tr._weights_changed                                      # version counters moved: the HIP copy is stale
+    model.load_state_dict(model.state_dict())                       # any in-place change counts, not only learn()
+    ex2 = tr.execute_parallel_episodes(4)
+    assert not tr._weights_changed and len(ex2) >= 4 * 10
+    view = tr.examples                                              # now the host view is built, once
+    assert view.states.shape == (len(ex), 3, 8, 8) and np.array_equal(view.policies, ex.policies)
+    assert tr.examples is view

@@ -176,3 +176,60 @@ def test_self_play_needs_the_gpu(tmp_path):
                          num_simulations=4, checkpoint_dir=str(tmp_path), verbose=False)
     with pytest.raises(Exception, match="GPU|libazamd"):
         tr.execute_parallel_episodes(2)
+
+
+def test_replay_ring_keeps_the_most_recent_rows_in_order():
+    """The ring against the reference's rule (append, keep the last max_examples;
+    src/parallel_trainer.py:437-442) on a stream of ragged appends that wraps several times,
+    with the cap lowered and raised in between."""
+    from alphazero_amd.parallel_trainer import ReplayRing
+    rs = np.random.RandomState(3)
+    ring = ReplayRing("cpu")
+    want = np.zeros((0,), np.float32)
+    tag = 0
+    limit = 1500
+    for step in range(60):
+        k = int(rs.choice([0, 1, 7, 300, 1100, 1700]))
+        vals = np.arange(tag, tag + k, dtype=np.float32)
+        tag += k
+        ex = ExampleArrays(np.broadcast_to(vals[:, None, None, None], (k, 3, 8, 8)).copy(),
+                           np.broadcast_to(vals[:, None], (k, 192)).copy(), np.broadcast_to(vals[:, None], (k, 2)).copy())
+        if step == 25:
+            limit = 400
+        if step == 40:
+            limit = 2500
+        ring.append(ex, limit)
+        want = np.concatenate([want, vals])[-limit:]
+        got = ring.ordered()
+        assert len(ring) == len(want) == len(got)
+        assert np.array_equal(got.policies[:, 0], want) and np.array_equal(got.states[:, 1, 2, 3], want)
+        assert np.array_equal(got.wls[:, 1], want)
+        if len(want):
+            idx = torch.tensor([0, len(want) - 1, len(want) // 2])
+            assert np.array_equal(ring.p[ring.physical(idx), 5].numpy(), want[idx.numpy()])
+    assert ring.rows <= 2500
+
+
+def test_learn_reads_a_wrapped_ring_like_a_flat_buffer(tmp_path):
+    """learn() on a ring whose storage has wrapped gives the weights of learn() on the same
+    examples held flat: the batches are gathered through the logical -> physical row map."""
+    ex = train_examples(40)
+
+    def trainer():
+        torch.manual_seed(123)
+        tr = ParallelTrainer(AlphaZeroNet(num_blocks=1, num_filters=8), device="cpu", checkpoint_dir=str(tmp_path),
+                             verbose=False)
+        tr.max_examples = 1024
+        return tr
+    wrapped = trainer()
+    for i in range(5):                                   # 5 x 281 rows into 1024: overrun, start moves
+        wrapped.add_examples(ExampleArrays.of((ex * 8)[i: i + 281]))
+    assert wrapped._replay.start != 0 and len(wrapped.examples) == 1024
+    flat = trainer()
+    flat.examples = wrapped.examples                     # the same 1024 examples, oldest first, from row 0
+    assert flat._replay.start == 0
+    assert np.array_equal(flat.examples.policies, wrapped.examples.policies)
+    for tr in (wrapped, flat):
+        torch.manual_seed(7)
+        tr.learn(epochs=1, batch_size=64)
+    assert all(torch.equal(a, b) for a, b in zip(wrapped.model.parameters(), flat.model.parameters()))
