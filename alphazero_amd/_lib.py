@@ -44,6 +44,7 @@ class SelfplayStats(C.Structure):
         ("moves", C.c_uint64),
         ("games_finished", C.c_uint64),
         ("samples_pending", C.c_uint64),
+        ("network_rows", C.c_uint64),
     ]
 
 

@@ -32,7 +32,10 @@ struct EngineView {
     uint32_t* leaf_node;
     uint64_t *leaf_mine, *leaf_theirs;
     int8_t* leaf_turn;
-    uint8_t* leaf_need;
+    uint8_t* leaf_need;   // [B] leaf must be evaluated; the buffer selection WRITES (and the step kernels read)
+    uint8_t* need_cur;    // [B] the same flags of the simulation being backed up.  The step API uses one
+                          // buffer for both; the fused search alternates between two, because the network
+                          // launch of simulation i+1 reads every game's new flag while it assigns its rows
     float* leaf_tv;
     uint16_t* path_len;
     uint32_t* path;       // [B][MAX_DEPTH]
@@ -48,8 +51,10 @@ struct EngineView {
     unsigned long long *stat_depth, *stat_descents;
     unsigned long long *stat_terminal, *stat_rootexp;  // terminal leaves backed up, roots expanded
     // Row of game g in the network's outputs (probabilities, values, head partial sums), or NULL
-    // when rows are games.  The fused search evaluates only the active games, packed densely,
-    // so that a shrinking set of games runs smaller, faster network launches.
+    // when rows are games.  The fused search evaluates only the leaves that need it (active
+    // games whose leaf is not terminal), packed densely in game order by the network launch
+    // itself, so that a shrinking set of games runs smaller, faster network launches and a
+    // terminal leaf costs no network row.
     const int32_t* row_of;
 };
 
@@ -152,8 +157,10 @@ struct az_engine {
     bool sp_ready = false;
     float* nn_probs = nullptr;   // [B][192]
     float* nn_values = nullptr;  // [B]
-    int32_t* row_of_dev = nullptr;   // [B] row of each active game in the packed network batch
-    int32_t* game_of_dev = nullptr;  // [B] the inverse: game of each row
+    uint8_t* need_buf[2] = {nullptr, nullptr};  // [B rounded up to 16] each; v.leaf_need / v.need_cur point into them
+    int32_t* row_of_dev = nullptr;   // [B] row of each evaluated game in the packed network batch
+    int32_t* n_rows_dev = nullptr;   // rows of the last network launch
+    unsigned long long* rows_total_dev = nullptr;  // rows of all network launches of the fused search
     uint64_t move_calls = 0;
 };
 

@@ -19,7 +19,8 @@ struct FinishParams {
     const float* wv2;  // [2][128]
     const float* bv2;  // [2]
     float* probs; float* value; float* policy_logits; float* wl_logits;
-    int B;
+    int B;                   // rows the partial sums are strided by
+    const int32_t* n_rows;   // rows in use when the tower assigned them on the device (else NULL: B)
 };
 
 __device__ __forceinline__ float head_wave_max(float v) {

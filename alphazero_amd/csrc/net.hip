@@ -76,7 +76,15 @@ constexpr int VALUE_K = 64 * VALUE_CH;         // 2048
 struct TowerParams {
     const uint64_t* mine;       // [B] canonical bitboards
     const uint64_t* theirs;
-    const int32_t* gather;      // position i is mine[gather[i]] / theirs[gather[i]]; NULL: i itself
+    // Row assignment on the device (the fused search): when `need` is given, the rows of the batch
+    // are the games whose flag is set, in game order; every workgroup finds its own rows by a
+    // scan over the flags, writes row_of[game] for them, and leaves at once if it has none.  B is
+    // then only the number of rows the grid was sized for (an upper bound).
+    const uint8_t* need;        // [n_games] 0/1, readable (zeros) up to the next multiple of 16
+    int n_games;
+    int32_t* row_of;            // out [n_games]: row of each game that has one
+    int32_t* n_rows;            // out: rows in use (written by the last workgroup)
+    unsigned long long* rows_total;  // += rows in use (NULL: not counted)
     int B;
     int blocks;
     const uint8_t* stem_w;      // [ks 2][nt 4][lane 64][16 B]
@@ -276,13 +284,83 @@ __device__ __forceinline__ void store_act(char* region, const f32x16 (&acc)[4][2
     }
 }
 
+
+// Row assignment of the fused search (see TowerParams::need).  Returns the game behind local
+// position lp of this workgroup (-1: none) and whether the workgroup has any row at all.
+// Every workgroup scans the flags from game 0 until it has passed its own rows (the last
+// workgroup scans them all and so knows the total); 16 flags per lane and pass.
+template <int THREADS, int PPB>
+__device__ __forceinline__ int assign_rows(const TowerParams& p, int tid, int lp, bool& has_rows) {
+    __shared__ uint32_t s_wave[THREADS / 64];
+    __shared__ int s_game[PPB];
+    const int lane = tid & 63, wave = tid >> 6;
+    const uint32_t row0 = blockIdx.x * PPB;
+    const bool last = blockIdx.x == gridDim.x - 1;
+    if (tid < PPB) s_game[tid] = -1;
+    uint32_t carry = 0;
+    const int padded = (p.n_games + 15) & ~15;
+    for (int base = 0; base < padded; base += THREADS * 16) {
+        const int g0 = base + tid * 16;
+        uint4 f = make_uint4(0u, 0u, 0u, 0u);
+        if (g0 < padded) f = *reinterpret_cast<const uint4*>(p.need + g0);
+        const uint32_t c = __popc(f.x & 0x01010101u) + __popc(f.y & 0x01010101u) + __popc(f.z & 0x01010101u) +
+                           __popc(f.w & 0x01010101u);
+        uint32_t incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        __syncthreads();   // s_game is initialised; the previous pass has read s_wave
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t before = carry, total = 0;
+#pragma unroll
+        for (int i = 0; i < THREADS / 64; ++i) {
+            const uint32_t x = s_wave[i];
+            total += x;
+            if (i < wave) before += x;
+        }
+        const uint32_t excl = before + incl - c;
+        if (c) {
+#pragma unroll
+            for (int j = 0; j < PPB; ++j) {
+                const uint32_t r = row0 + j;
+                if (r >= excl && r < excl + c) {
+                    int k = (int)(r - excl), idx = -1;   // the k-th set flag of this lane's 16
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const uint32_t word = (q < 4) ? f.x : ((q < 8) ? f.y : ((q < 12) ? f.z : f.w));
+                        if ((word >> ((q & 3) * 8)) & 1u) {
+                            if (k == 0 && idx < 0) idx = q;
+                            --k;
+                        }
+                    }
+                    s_game[j] = g0 + idx;
+                    p.row_of[g0 + idx] = (int32_t)r;
+                }
+            }
+        }
+        carry += total;
+        if (!last && carry >= row0 + PPB) break;
+    }
+    if (last && tid == 0) {
+        *p.n_rows = (int32_t)carry;
+        if (p.rows_total) atomicAdd(p.rows_total, (unsigned long long)carry);
+    }
+    __syncthreads();
+    has_rows = s_game[0] >= 0;
+    return s_game[lp];
+}
+
 __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
     __shared__ __attribute__((aligned(1024))) char lds[LDS_TOTAL];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
     const int pos = blockIdx.x * 4 + wave;
-    const bool live = pos < p.B;
+    bool live = pos < p.B;
+    int assigned = -1;
     char* region0 = lds + wave * ACT_REGION;
     const int nconv = 2 * p.blocks + 1;
     const int total_taps = nconv * 9;
@@ -318,6 +396,12 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
     };
     prefetch(0);
     prefetch_bias(0);
+    if (p.need) {
+        bool has_rows;
+        assigned = assign_rows<256, 4>(p, tid, wave, has_rows);
+        if (!has_rows) { wait_weights(); return; }   // no copy into LDS may outlive the workgroup
+        live = assigned >= 0;
+    }
 
     // per-tap fragment addresses (bytes from the LDS base) for the two pixel tiles.  An
     // out-of-board pixel reads zeros from the 512-byte zero area, at the offset that falls on the
@@ -342,7 +426,7 @@ __global__ __launch_bounds__(256, 1) void k_tower(TowerParams p) {
 
     // ---------------- stem: 3x3 conv over the 3 input planes, K = 27 padded to 32
     {
-        const int src_pos = (live && p.gather) ? p.gather[pos] : pos;
+        const int src_pos = p.need ? assigned : pos;
         const uint64_t mine = live ? p.mine[src_pos] : 0ull, theirs = live ? p.theirs[src_pos] : 0ull;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
@@ -691,7 +775,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_tower_split(TowerParams p) {
     const int cw = wave_u % WPP;            // its channel group
     const int nt0 = cw * NT;                // first channel tile of the group
     const int pos = blockIdx.x * PPW + lp;
-    const bool live = pos < p.B;
+    bool live = pos < p.B;
+    int assigned = -1;
     char* region = lds + lp * ACT_REGION;
     // floats: [0,128) channel means, [128 + 16 cw, +16) hidden layer (per wave), [192,320) gates, [320,448) shifts.
     // With spare activation regions (WAVES = 4) it lives there; otherwise in the position's own
@@ -735,6 +820,12 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_tower_split(TowerParams p) {
         for (int t = 0; t < AHEAD; ++t) prefetch(t, t);
     }
     prefetch_bias(0);
+    if (p.need) {
+        bool has_rows;
+        assigned = assign_rows<WAVES * 64, PPW>(p, tid, lp, has_rows);
+        if (!has_rows) { wait_weights(); return; }   // no copy into LDS may outlive the workgroup
+        live = assigned >= 0;
+    }
 
     uint32_t aaddr[9][2];
 #pragma unroll
@@ -755,7 +846,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void k_tower_split(TowerParams p) {
 
     // ---------------- stem
     {
-        const int src_pos = (live && p.gather) ? p.gather[pos] : pos;
+        const int src_pos = p.need ? assigned : pos;
         const uint64_t mine = live ? p.mine[src_pos] : 0ull, theirs = live ? p.theirs[src_pos] : 0ull;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -1129,6 +1220,7 @@ struct HeadParams {
     float* part_p;         // [8][B][192]
     float* part_v;         // [2][B][128]
     int B;
+    const int32_t* n_rows; // rows in use when the tower assigned them itself (else NULL: B)
 };
 
 // A workgroup covers HEAD_MT x 16 positions and one K chunk; wave w owns NTW n-tiles.
@@ -1197,6 +1289,7 @@ __device__ __forceinline__ void head_gemm_body(const __bf16* act, int K, const u
 __global__ __launch_bounds__(256) void k_head_gemm(HeadParams p) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tile = blockIdx.x, c = blockIdx.y;
+    if (p.n_rows && tile * 16 * HEAD_MT >= *p.n_rows) return;   // no position of this tile is in use
     if (c < POLICY_CHUNKS)
         head_gemm_body<3, 12>(p.p_act, POLICY_K, p.wp, p.part_p, NUM_ACTIONS, p.B, c, tile, wave, lane);
     else
@@ -1207,7 +1300,7 @@ __global__ __launch_bounds__(256) void k_head_gemm(HeadParams p) {
 __global__ __launch_bounds__(256) void k_head_finish(FinishParams p) {
     const int lane = threadIdx.x & 63;
     const int pos = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (pos >= p.B) return;
+    if (pos >= p.B || (p.n_rows && pos >= *p.n_rows)) return;
     float pr[3];
     const float value = dev_head_finish(p, pos, lane, pr);
 #pragma unroll
@@ -1555,12 +1648,19 @@ extern "C" int az_net_load_state(az_net* n, const float* s, int64_t count) {
 
 // tower + head GEMMs: leaves the split-K partial sums in hb
 static int forward_partial(az_net* n, int32_t B, const uint64_t* mine_dev, const uint64_t* theirs_dev,
-                           const int32_t* gather_dev, const HeadBuffers& hb, hipStream_t s) {
+                           const RowAssign* rows, const HeadBuffers& hb, hipStream_t s) {
     AZ_CHECK_ARG(n && n->loaded, "az_net_forward: network has no weights (call az_net_load_state)");
     if (B == 0) return AZ_OK;
     AZ_CHECK_ARG(mine_dev && theirs_dev, "az_net_forward: null pointer");
     TowerParams tp;
-    tp.mine = mine_dev; tp.theirs = theirs_dev; tp.gather = gather_dev; tp.B = B; tp.blocks = n->blocks;
+    tp.mine = mine_dev; tp.theirs = theirs_dev; tp.B = B; tp.blocks = n->blocks;
+    tp.need = nullptr; tp.n_games = 0; tp.row_of = nullptr; tp.n_rows = nullptr; tp.rows_total = nullptr;
+    if (rows) {
+        AZ_CHECK_ARG(rows->need && rows->row_of && rows->n_rows && rows->n_games >= B,
+                     "az_net_forward: incomplete row assignment");
+        tp.need = rows->need; tp.n_games = rows->n_games; tp.row_of = rows->row_of; tp.n_rows = rows->n_rows;
+        tp.rows_total = rows->rows_total;
+    }
     tp.stem_w = n->stem_w; tp.stem_b = n->stem_b; tp.conv_w = n->conv_w; tp.conv_b = n->conv_b;
     tp.se_img = n->se_img;
     tp.value_w = n->value_w; tp.value_b = n->value_b; tp.p_act = hb.p_act; tp.v_act = hb.v_act;
@@ -1580,23 +1680,23 @@ static int forward_partial(az_net* n, int32_t B, const uint64_t* mine_dev, const
     else if (form == 8) hipLaunchKernelGGL((k_tower_split<2, 8>), dim3((B + 3) / 4), dim3(512), 0, s, tp);
     else hipLaunchKernelGGL(k_tower, dim3((B + 3) / 4), dim3(256), 0, s, tp);
     if (stamp) AZ_HIP(hipEventRecord(n->ev1[n->ev_used++], s));
-    HeadParams hp{hb.p_act, hb.v_act, n->wp, n->wv, hb.part_p, hb.part_v, B};
+    HeadParams hp{hb.p_act, hb.v_act, n->wp, n->wv, hb.part_p, hb.part_v, B, tp.n_rows};
     hipLaunchKernelGGL(k_head_gemm, dim3((B + 16 * HEAD_MT - 1) / (16 * HEAD_MT), POLICY_CHUNKS + VALUE_CHUNKS), dim3(256), 0, s, hp);
     AZ_HIP(hipGetLastError());
     return AZ_OK;
 }
 
-static FinishParams finish_params(az_net* n, int32_t B, const HeadBuffers& hb) {
-    return FinishParams{hb.part_p, hb.part_v, n->bp, n->bv1, n->wv2, n->bv2, nullptr, nullptr, nullptr, nullptr, B};
+static FinishParams finish_params(az_net* n, int32_t B, const HeadBuffers& hb, const int32_t* n_rows) {
+    return FinishParams{hb.part_p, hb.part_v, n->bp, n->bv1, n->wv2, n->bv2, nullptr, nullptr, nullptr, nullptr, B, n_rows};
 }
 
 static int forward_full(az_net* n, int32_t B, const uint64_t* mine_dev, const uint64_t* theirs_dev,
-                        const int32_t* gather_dev, const HeadBuffers& hb, float* probs_dev, float* value_dev,
+                        const RowAssign* rows, const HeadBuffers& hb, float* probs_dev, float* value_dev,
                         float* policy_logits_dev, float* wl_logits_dev, hipStream_t s) {
-    const int rc = forward_partial(n, B, mine_dev, theirs_dev, gather_dev, hb, s);
+    const int rc = forward_partial(n, B, mine_dev, theirs_dev, rows, hb, s);
     if (rc != AZ_OK || B == 0) return rc;
     AZ_CHECK_ARG(probs_dev && value_dev, "az_net_forward: null pointer");
-    FinishParams fp = finish_params(n, B, hb);
+    FinishParams fp = finish_params(n, B, hb, rows ? rows->n_rows : nullptr);
     fp.probs = probs_dev; fp.value = value_dev; fp.policy_logits = policy_logits_dev; fp.wl_logits = wl_logits_dev;
     hipLaunchKernelGGL(k_head_finish, dim3((B + 3) / 4), dim3(256), 0, s, fp);
     AZ_HIP(hipGetLastError());
@@ -1604,20 +1704,22 @@ static int forward_full(az_net* n, int32_t B, const uint64_t* mine_dev, const ui
 }
 
 int az::net_forward_partial(az_net* n, int32_t B, const uint64_t* mine_dev, const uint64_t* theirs_dev,
-                            const int32_t* gather_dev, hipStream_t s) {
+                            const RowAssign* rows, hipStream_t s) {
     AZ_CHECK_ARG(n, "az_net_forward: null network");
     AZ_CHECK_ARG(B >= 0 && B <= n->max_batch, "az_net_forward: batch %d exceeds max_batch %d", B, n->max_batch);
-    return forward_partial(n, B, mine_dev, theirs_dev, gather_dev, n->own(), s);
+    return forward_partial(n, B, mine_dev, theirs_dev, rows, n->own(), s);
 }
 
-az::FinishParams az::net_finish_params(az_net* n, int32_t B) { return finish_params(n, B, n->own()); }
+az::FinishParams az::net_finish_params(az_net* n, int32_t B, const int32_t* n_rows) {
+    return finish_params(n, B, n->own(), n_rows);
+}
 
 int az::net_forward_full(az_net* n, int32_t B, const uint64_t* mine_dev, const uint64_t* theirs_dev,
-                         const int32_t* gather_dev, float* probs_dev, float* value_dev, float* policy_logits_dev,
+                         const RowAssign* rows, float* probs_dev, float* value_dev, float* policy_logits_dev,
                          float* wl_logits_dev, hipStream_t s) {
     AZ_CHECK_ARG(n, "az_net_forward: null network");
     AZ_CHECK_ARG(B >= 0 && B <= n->max_batch, "az_net_forward: batch %d exceeds max_batch %d", B, n->max_batch);
-    return forward_full(n, B, mine_dev, theirs_dev, gather_dev, n->own(), probs_dev, value_dev, policy_logits_dev,
+    return forward_full(n, B, mine_dev, theirs_dev, rows, n->own(), probs_dev, value_dev, policy_logits_dev,
                         wl_logits_dev, s);
 }
 

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(64) void k_tree_step(EngineView E, FinishParams F, 
     const int g = blockIdx.x, lane = threadIdx.x;
     // ---- load stage 1
     const int active = E.active[g];
-    const int need = E.leaf_need[g];
+    const int need = E.need_cur[g];
     float v = E.leaf_tv[g];
     const SelectStart st = load_select_start(E, g);
     const size_t pool = pool_base(E, g);
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(64) void k_tree_step(EngineView E, FinishParams F, 
     lf.node = E.leaf_node[g]; lf.mine = E.leaf_mine[g]; lf.theirs = E.leaf_theirs[g];
     lf.turn = E.leaf_turn[g]; lf.used = E.used[g];
     HeadOperands ho;
-    const int row = E.row_of ? E.row_of[g] : g;
+    const int row = (E.row_of && need) ? E.row_of[g] : g;   // written by this simulation's network launch
     if (need) ho = head_load(F, row, lane);
     // ---- load stage 2
     const bool on_path = lane < len;
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(64) void k_tree_step(EngineView E, FinishParams F, 
         E.N[n] = E.N[n] + 1;
         E.W[n] = E.W[n] + vv;
     }
-    if (lane == 0) { E.stat_descents[g] = stat_descents + 1ull; E.leaf_need[g] = 0; }
+    if (lane == 0) { E.stat_descents[g] = stat_descents + 1ull; E.need_cur[g] = 0; }
     if (!do_select) return;
     __syncthreads();  // this wave's tree updates are visible to its own descent
     if (len == 1) {
@@ -331,7 +331,7 @@ static int selfplay_alloc(az_engine* e) {
     AZ_ALLOC(S.q_count, 1); AZ_ALLOC(S.stat, 4);
     AZ_ALLOC(S.fin_base, B); AZ_ALLOC(S.fin_flag, B);
     AZ_ALLOC(e->nn_probs, B * 192); AZ_ALLOC(e->nn_values, B);
-    AZ_ALLOC(e->row_of_dev, B); AZ_ALLOC(e->game_of_dev, B);
+    AZ_ALLOC(e->row_of_dev, B); AZ_ALLOC(e->n_rows_dev, 1); AZ_ALLOC(e->rows_total_dev, 1);
 #undef AZ_ALLOC
     e->sp_ready = true;
     return AZ_OK;
@@ -350,23 +350,18 @@ static int check_sticky(az_engine* e, hipStream_t s) { return az::check_engine_e
 
 // MCTS.search_batch (src/mcts.py:94-189) with the attached network.  Per simulation
 // three launches: tower, head GEMMs, k_tree_step.
-// Packs the active games into rows 0 .. M-1 of the network batch.  Returns M; with every
-// game active rows are games and no index is used.
-static int pack_active_rows(az_engine* e, hipStream_t s, int* rows_out) {
+// The network evaluates only the leaves that need it: the tower assigns its rows from the
+// games' flags on the device (RowAssign), so neither inactive games nor terminal leaves
+// (src/mcts.py:183-187: backed up without an evaluation) occupy rows.  The host only
+// sizes the launches, by the number of active games.
+static int count_active(az_engine* e, hipStream_t s, int* rows_out) {
     const int B = e->v.B;
     std::vector<uint8_t> active(B);
     AZ_HIP(hipMemcpyAsync(active.data(), e->v.active, B, hipMemcpyDeviceToHost, s));
     AZ_HIP(hipStreamSynchronize(s));
-    std::vector<int32_t> row_of(B, 0), game_of(B, 0);
     int M = 0;
-    for (int g = 0; g < B; ++g)
-        if (active[g]) { row_of[g] = M; game_of[M] = g; ++M; }
+    for (int g = 0; g < B; ++g) M += active[g] ? 1 : 0;
     *rows_out = M;
-    if (M == B || M == 0) { e->v.row_of = nullptr; return AZ_OK; }
-    AZ_HIP(hipMemcpyAsync(e->row_of_dev, row_of.data(), B * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    AZ_HIP(hipMemcpyAsync(e->game_of_dev, game_of.data(), B * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    AZ_HIP(hipStreamSynchronize(s));  // the host vectors go out of scope
-    e->v.row_of = e->row_of_dev;
     return AZ_OK;
 }
 
@@ -374,22 +369,37 @@ static int search_async(az_engine* e, int num_simulations, int add_noise, hipStr
     if (!e->net) AZ_FAIL(AZ_ERR_STATE, "no network attached (az_engine_attach_net)");
     const int B = e->v.B;
     int rc, M = 0;
-    if ((rc = pack_active_rows(e, s, &M))) return rc;
+    if ((rc = count_active(e, s, &M))) return rc;
     if (M == 0) return AZ_OK;                       // no active game: nothing to search
-    const int32_t* gather = e->v.row_of ? e->game_of_dev : nullptr;
-    // every kernel launched below takes e->v by value, so the row index is dropped again
-    // before returning: the step API feeds per-game rows
-    struct Restore { az_engine* e; ~Restore() { e->v.row_of = nullptr; } } restore{e};
+    EngineView& V = e->v;
+    // every kernel launched below takes V by value; the step API's view (one flag buffer, rows
+    // are games) is put back before returning
+    struct Restore {
+        az_engine* e;
+        ~Restore() { e->v.row_of = nullptr; e->v.leaf_need = e->v.need_cur = e->need_buf[0]; }
+    } restore{e};
+    V.row_of = e->row_of_dev;
+    RowAssign rows{nullptr, B, e->row_of_dev, e->n_rows_dev, e->rows_total_dev};
+    // roots: flags in buffer 1, which is all zero again once the roots are expanded
+    V.leaf_need = V.need_cur = e->need_buf[1];
+    rows.need = e->need_buf[1];
     if ((rc = az_engine_roots_prepare(e, nullptr, nullptr, s))) return rc;
-    if ((rc = az::net_forward_full(e->net, M, e->v.leaf_mine, e->v.leaf_theirs, gather, e->nn_probs, e->nn_values,
+    if ((rc = az::net_forward_full(e->net, M, V.leaf_mine, V.leaf_theirs, &rows, e->nn_probs, e->nn_values,
                                    nullptr, nullptr, s))) return rc;
     if ((rc = az_engine_roots_expand(e, e->nn_probs, s))) return rc;
     if (add_noise && (rc = az_engine_add_noise(e, nullptr, s))) return rc;
+    // simulation i reads its flags from buffer i & 1 and selection writes the next ones into the
+    // other buffer: the network launch of simulation i + 1 reads ALL games' flags while
+    // k_tree_step blocks of simulation i may still be running ahead of one another
+    V.leaf_need = V.need_cur = e->need_buf[0];
     if (num_simulations > 0 && (rc = az_engine_select(e, nullptr, nullptr, s))) return rc;
-    const FinishParams fin = az::net_finish_params(e->net, M);
+    const FinishParams fin = az::net_finish_params(e->net, M, e->n_rows_dev);
     for (int i = 0; i < num_simulations; ++i) {
-        if ((rc = az::net_forward_partial(e->net, M, e->v.leaf_mine, e->v.leaf_theirs, gather, s))) return rc;
-        hipLaunchKernelGGL(k_tree_step, dim3(B), dim3(64), 0, s, e->v, fin, i + 1 < num_simulations ? 1 : 0);
+        rows.need = e->need_buf[i & 1];
+        if ((rc = az::net_forward_partial(e->net, M, V.leaf_mine, V.leaf_theirs, &rows, s))) return rc;
+        V.need_cur = e->need_buf[i & 1];
+        V.leaf_need = e->need_buf[(i + 1) & 1];
+        hipLaunchKernelGGL(k_tree_step, dim3(B), dim3(64), 0, s, V, fin, i + 1 < num_simulations ? 1 : 0);
     }
     AZ_HIP(hipGetLastError());
     e->phase = PHASE_IDLE;
@@ -498,5 +508,9 @@ extern "C" int az_engine_selfplay_stats(az_engine* e, az_selfplay_stats* out, vo
     // every descent that did not end in a terminal leaf was evaluated, plus the root expansions
     out->simulations = sims; out->nn_evals = sims - term + rootexp; out->moves = st[0]; out->games_finished = st[1];
     out->samples_pending = q;
+    unsigned long long rows = 0;
+    AZ_HIP(hipMemcpyAsync(&rows, e->rows_total_dev, sizeof rows, hipMemcpyDeviceToHost, s));
+    AZ_HIP(hipStreamSynchronize(s));
+    out->network_rows = rows;
     return AZ_OK;
 }

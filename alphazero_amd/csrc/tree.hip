@@ -75,11 +75,11 @@ __global__ __launch_bounds__(64) void k_expand_backup(EngineView E, const float*
     __shared__ uint8_t s_a[MAX_CHILDREN];
     const int g = blockIdx.x, lane = threadIdx.x;
     if (!E.active[g]) return;
-    const int need = E.leaf_need[g];
-    const int row = E.row_of ? E.row_of[g] : g;
+    const int need = E.need_cur[g];
+    const int row = (E.row_of && need) ? E.row_of[g] : g;
     if (need) dev_expand(E, g, lane, probs + (size_t)row * 192, s_p, s_a);
     if (do_backup) dev_backup(E, g, lane, need ? values[row] : E.leaf_tv[g]);
-    if (lane == 0) E.leaf_need[g] = 0;
+    if (lane == 0) E.need_cur[g] = 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -322,7 +322,12 @@ static int engine_alloc(az_engine* e) {
     AZ_ALLOC(V.active, B); AZ_ALLOC(V.ply, B); AZ_ALLOC(V.root, B); AZ_ALLOC(V.used, B);
     AZ_ALLOC(V.root_mode, B); AZ_ALLOC(V.root_p64, B * 48);
     AZ_ALLOC(V.leaf_node, B); AZ_ALLOC(V.leaf_mine, B); AZ_ALLOC(V.leaf_theirs, B);
-    AZ_ALLOC(V.leaf_turn, B); AZ_ALLOC(V.leaf_need, B); AZ_ALLOC(V.leaf_tv, B);
+    AZ_ALLOC(V.leaf_turn, B); AZ_ALLOC(V.leaf_tv, B);
+    // two flag buffers, each readable as zeros up to the next multiple of 16 games
+    uint8_t *flags0 = nullptr, *flags1 = nullptr;
+    AZ_ALLOC(flags0, (B + 31) & ~(size_t)15); AZ_ALLOC(flags1, (B + 31) & ~(size_t)15);
+    e->need_buf[0] = flags0; e->need_buf[1] = flags1;
+    V.leaf_need = V.need_cur = flags0;
     AZ_ALLOC(V.path_len, B); AZ_ALLOC(V.path, B * MAX_DEPTH);
     AZ_ALLOC(V.arena, B);
 #define AZ_ALLOC_RAW(ptr, count)                                                      \

@@ -310,4 +310,5 @@ class Engine:
         st = _lib.SelfplayStats()
         check(_lib.lib().az_engine_selfplay_stats(self.h, C.byref(st), _stream(self.device)))
         return dict(simulations=st.simulations, nn_evals=st.nn_evals, moves=st.moves,
-                    games_finished=st.games_finished, samples_pending=st.samples_pending)
+                    games_finished=st.games_finished, samples_pending=st.samples_pending,
+                    network_rows=st.network_rows)

@@ -378,11 +378,11 @@ def main():
         exchange = exchange_block(args, dist, model, rank, world, coll_dev, backend, barrier)
 
     if rank == 0:
-        # rows the tower computed vs rows whose result was used: every launch of the timed
-        # region carried `games` rows; a row whose leaf was terminal needs no evaluation
-        rows_launched = float(args.steps) * (args.sims + 1) * args.games * world
-        used_fraction = min(1.0, evals / rows_launched) if rows_launched else 0.0
-        flop_launch = tower_flop_per_position(args.blocks) * args.games * used_fraction
+        # rows per tower launch: the launches of the timed region carried exactly the evaluated
+        # leaves (terminal leaves take no row), `evals` rows over steps x (sims + 1) launches per rank
+        launches = float(args.steps) * (args.sims + 1) * world
+        rows_per_launch = evals / launches if launches else 0.0
+        flop_launch = tower_flop_per_position(args.blocks) * rows_per_launch
         # HBM-side bytes per tower launch come from separate rocprofv3 --pmc passes
         # (profiles/): counters cannot be read from inside this process
         traffic, traffic_source = None, None
@@ -418,7 +418,7 @@ def main():
                          "kernel": "k_tower" if args.games > 512 else ("k_tower_split<2>" if args.games > 256 else "k_tower_split<1>"),
                          "launch_ms": tower_ms, "launch_samples": tower_samples,
                          "flop_per_launch": flop_launch,
-                         "rows_per_launch": args.games, "rows_used_fraction": used_fraction,
+                         "rows_per_launch": rows_per_launch,
                          "mean_search_depth": depth},
         }
         if exchange is not None:

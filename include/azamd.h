@@ -241,6 +241,8 @@ typedef struct {
     uint64_t moves;           /* plies played */
     uint64_t games_finished;
     uint64_t samples_pending; /* finished-game samples waiting in the queue */
+    uint64_t network_rows;    /* positions the network launches of the fused search actually computed:
+                                 equals nn_evals (terminal leaves and idle games take no row) */
 } az_selfplay_stats;
 
 int az_engine_attach_net(az_engine* e, az_net* n);

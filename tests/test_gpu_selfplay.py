@@ -357,3 +357,63 @@ def test_packed_samples_unpack_to_the_drained_arrays(small_model):
     for g, w in zip(sub, want):
         assert np.array_equal(g, w[pick.cpu().numpy()])
     assert unpack_samples(packed[:0])[0].shape == (0, 3, 8, 8)
+
+
+def test_network_rows_are_exactly_the_evaluated_leaves(small_model):
+    """The network launches of the fused search carry one row per leaf that needs an evaluation:
+    idle games and terminal leaves (backed up without the network, src/mcts.py:183-187) take
+    none.  Late in a game most simulations end in terminal leaves."""
+    from alphazero_amd.engine import Engine
+    from alphazero_amd.model import HipInference
+    nG, S = 37, 200                                   # not a multiple of 16 or of 4
+    w, b, t, win = orc.random_positions(4000, seed=5)
+    # a piece one step from its goal row: wins are one or two plies below the root
+    late = [i for i in range(4000) if win[i] == 0 and ((int(w[i]) >> 48) & 0xFF or (int(b[i]) >> 8) & 0xFF)
+            and orc.legal_actions(orc.make_pos(w[i], b[i], t[i])).size][:nG]
+    assert len(late) == nG
+    e = Engine(nG, pool_nodes_per_game=1 << 15)
+    e.attach_net(HipInference(small_model, max_batch=64))
+    e.set_positions(np.arange(nG), w[late], b[late], t[late])
+    active = np.ones(nG, np.uint8)
+    active[[3, 11, 36]] = 0
+    e.set_active(active)
+    e.search(S, add_noise=True)
+    st = e.stats()
+    assert st["simulations"] == 34 * S
+    assert st["network_rows"] == st["nn_evals"]
+    assert st["nn_evals"] < 0.9 * (st["simulations"] + 34)        # many leaves were terminal
+    assert st["nn_evals"] >= 34                                     # every root was evaluated once
+
+
+def test_fused_search_with_more_games_than_one_scan_pass(small_model):
+    """Row assignment scans 16 flags per lane and pass (4096 games per pass for the 256-lane tower
+    forms): an engine with more games than that must give the trees of the step API too."""
+    from alphazero_amd.engine import Engine
+    from alphazero_amd.model import HipInference
+    nG, S = 4100 + 64, 3
+    inf = HipInference(small_model, max_batch=nG)
+    w, b, t, win = orc.random_positions(nG + 600, seed=17)
+    idx = [i for i in range(len(w)) if win[i] == 0][:nG]
+    rs = np.random.RandomState(2)
+    active = (rs.rand(nG) < 0.8).astype(np.uint8)
+    active[-1] = active[0] = active[4095] = active[4096] = 1
+    fused, step = Engine(nG, pool_nodes_per_game=256), Engine(nG, pool_nodes_per_game=256)
+    for e in (fused, step):
+        e.set_positions(np.arange(nG), w[idx], b[idx], t[idx])
+        e.set_active(active)
+    fused.attach_net(inf)
+    fused.search(S, add_noise=False)
+    start = torch.from_numpy(orc.encode_state(orc.start_position())).cuda()
+
+    def evaluate(planes, need):
+        x = planes.clone()
+        x[need == 0] = start
+        probs, value, _, _ = inf.forward_planes(x)
+        return probs, value
+    step.search_with(evaluate, S)
+    slots = np.flatnonzero(active)
+    for a, o in zip(fused.roots_children(slots), step.roots_children(slots)):
+        assert np.array_equal(a["actions"], o["actions"]) and np.array_equal(a["N"], o["N"])
+        assert np.array_equal(a["W"].view(np.uint32), o["W"].view(np.uint32))
+    st = fused.stats()
+    assert st["network_rows"] == st["nn_evals"]
