@@ -21,6 +21,6 @@ run_pass tower_sq SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INST
 run_pass tower_lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS -- $NET || exit 1
 run_pass movegen_fetch FETCH_SIZE -- $MOV || exit 1
 run_pass movegen_write WRITE_SIZE -- $MOV || exit 1
-run_pass selfplay_fetch FETCH_SIZE -- python3 bench.py --steps 1 --warmup 0 --sims 100 --cpu-seconds 0 || exit 1
-run_pass selfplay_write WRITE_SIZE -- python3 bench.py --steps 1 --warmup 0 --sims 100 --cpu-seconds 0 || exit 1
+run_pass selfplay_fetch FETCH_SIZE -- python3 bench.py --steps 1 --warmup 0 --sims 100 --cpu-seconds 0 --no-secondary || exit 1
+run_pass selfplay_write WRITE_SIZE -- python3 bench.py --steps 1 --warmup 0 --sims 100 --cpu-seconds 0 --no-secondary || exit 1
 echo done
