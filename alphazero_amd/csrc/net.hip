@@ -1535,6 +1535,9 @@ extern "C" int az_net_load_state(az_net* n, const float* s, int64_t count) {
     AZ_CHECK_ARG(count == expect, "az_net_load_state: got %lld floats, a %d x 128 network has %lld", (long long)count,
                  nb, (long long)expect);
     AZ_HIP(hipSetDevice(n->device));
+    // the uploads below are blocking copies on the null stream: forwards the caller queued on
+    // other streams must have finished reading the old weights first
+    AZ_HIP(hipDeviceSynchronize());
     const float* q = s;
     auto take = [&](int64_t k) { const float* r = q; q += k; return r; };
     int rc;

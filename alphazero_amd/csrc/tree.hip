@@ -122,7 +122,12 @@ __global__ __launch_bounds__(64) void k_add_noise(EngineView E, const double* no
 }
 
 // ---------------------------------------------------------------------------
-// get_action_probs (src/mcts.py:191-225), temperature 0 or 1
+// get_action_probs (src/mcts.py:191-225).  Temperatures 0 and 1 (the trainer's schedule,
+// src/parallel_trainer.py:164) are bit-exact: an argmax, and count / total with both exactly
+// representable.  Any other temperature follows the same formula, count ** (1 / T) / sum, in
+// float32 with the device's powf and a fixed summation order; numpy's powf and pairwise
+// sum differ from it in the last bits, so that case is equal to the reference within
+// rounding (relative 1e-5), not bit for bit.
 __global__ __launch_bounds__(64) void k_action_probs(EngineView E, const float* temps,
                                                      float* probs_out) {
     __shared__ float row[192];
@@ -132,7 +137,8 @@ __global__ __launch_bounds__(64) void k_action_probs(EngineView E, const float* 
     const uint32_t r = E.root[g];
     int k = 0; uint32_t fc = 0;
     if (r != NODE_NONE) { k = (E.IN[pool + r] >> 8) & 0xFF; fc = E.FC[pool + r]; }
-    const bool t0 = temps ? (temps[g] == 0.0f) : (E.ply[g] >= E.temp_thr);
+    const float temp = temps ? temps[g] : ((E.ply[g] >= E.temp_thr) ? 0.0f : 1.0f);
+    const bool t0 = (temp == 0.0f);
     for (int i = lane; i < 192; i += 64) row[i] = 0.f;
     __syncthreads();
     uint32_t cnt = 0; int a = 0;
@@ -148,8 +154,14 @@ __global__ __launch_bounds__(64) void k_action_probs(EngineView E, const float* 
         }
         const int best = ((key >> 8) == 0) ? 0 : (255 - (int)(key & 0xFF));
         if (lane == 0) row[best] = 1.0f;
-    } else if (lane < k) {
-        row[a] = (total > 0) ? ((float)cnt / (float)total) : (float)(1.0 / (double)k);
+    } else if (temp == 1.0f) {
+        if (lane < k) row[a] = (total > 0) ? ((float)cnt / (float)total) : (float)(1.0 / (double)k);
+    } else {
+        const float powered = (lane < k) ? powf((float)cnt, 1.0f / temp) : 0.0f;
+        float sum = powered;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if (lane < k) row[a] = (sum > 0) ? (powered / sum) : (float)(1.0 / (double)k);
     }
     __syncthreads();
     for (int i = lane; i < 192; i += 64) probs_out[(size_t)g * 192 + i] = row[i];
@@ -620,8 +632,7 @@ extern "C" int az_engine_action_probs(az_engine* e, const float* temps_host, flo
     const float* temps_dev = nullptr;
     if (temps_host) {
         for (int i = 0; i < e->v.B; ++i)
-            AZ_CHECK_ARG(temps_host[i] == 0.0f || temps_host[i] == 1.0f,
-                         "az_engine_action_probs: temperature %g (only 0 and 1 are supported)", temps_host[i]);
+            AZ_CHECK_ARG(temps_host[i] >= 0.0f, "az_engine_action_probs: negative temperature %g", temps_host[i]);
         AZ_HIP(hipMemcpyAsync(e->stage_temps, temps_host, e->v.B * sizeof(float), hipMemcpyHostToDevice, s));
         temps_dev = e->stage_temps;
     }

@@ -54,14 +54,19 @@ class Engine:
                                 float(dirichlet_epsilon), int(temperature_threshold),
                                 int(pool_nodes_per_game), int(seed), self.device.index)
         h = C.c_void_p()
-        with torch.cuda.device(self.device):
-            check(_lib.lib().az_engine_create(C.byref(h), C.byref(cfg)))
+        self._call("az_engine_create", C.byref(h), C.byref(cfg))
         self.h = h
         self.planes = torch.zeros((self.n, 3, 8, 8), dtype=torch.float32, device=self.device)
         self.need = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
         self.probs = torch.zeros((self.n, 192), dtype=torch.float32, device=self.device)
         self.values = torch.zeros(self.n, dtype=torch.float32, device=self.device)
         self.net = None
+
+    def _call(self, name, *args):
+        """One libazamd entry point with this engine's GPU current (kernels are launched on the
+        current device; the stream passed along is that device's current stream)."""
+        with torch.cuda.device(self.device):
+            check(getattr(_lib.lib(), name)(*args))
 
     def close(self):
         if getattr(self, "h", None):
@@ -81,10 +86,9 @@ class Engine:
         black = np.ascontiguousarray(black, np.uint64)
         turn = np.ascontiguousarray(turn, np.int8)
         winner = None if winner is None else np.ascontiguousarray(winner, np.int8)
-        with torch.cuda.device(self.device):
-            check(_lib.lib().az_engine_set_positions(
-                self.h, len(slots), _host_ptr(slots), _host_ptr(white), _host_ptr(black),
-                _host_ptr(turn), _host_ptr(winner), _stream(self.device)))
+        self._call("az_engine_set_positions",
+            self.h, len(slots), _host_ptr(slots), _host_ptr(white), _host_ptr(black),
+            _host_ptr(turn), _host_ptr(winner), _stream(self.device))
 
     def update_positions(self, slots, white, black, turn, winner=None):
         """Like set_positions but keeps the trees."""
@@ -93,15 +97,13 @@ class Engine:
         black = np.ascontiguousarray(black, np.uint64)
         turn = np.ascontiguousarray(turn, np.int8)
         winner = None if winner is None else np.ascontiguousarray(winner, np.int8)
-        with torch.cuda.device(self.device):
-            check(_lib.lib().az_engine_update_positions(
-                self.h, len(slots), _host_ptr(slots), _host_ptr(white), _host_ptr(black),
-                _host_ptr(turn), _host_ptr(winner), _stream(self.device)))
+        self._call("az_engine_update_positions",
+            self.h, len(slots), _host_ptr(slots), _host_ptr(white), _host_ptr(black),
+            _host_ptr(turn), _host_ptr(winner), _stream(self.device))
 
     def root_counts(self):
         k = np.zeros(self.n, np.int32)
-        with torch.cuda.device(self.device):
-            check(_lib.lib().az_engine_root_counts(self.h, _host_ptr(k), _stream(self.device)))
+        self._call("az_engine_root_counts", self.h, _host_ptr(k), _stream(self.device))
         return k
 
     def reset_all(self):
@@ -114,24 +116,22 @@ class Engine:
         black = np.zeros(self.n, np.uint64)
         turn = np.zeros(self.n, np.int8)
         winner = np.zeros(self.n, np.int8)
-        with torch.cuda.device(self.device):
-            check(_lib.lib().az_engine_get_positions(self.h, _host_ptr(white), _host_ptr(black),
-                                                     _host_ptr(turn), _host_ptr(winner), _stream(self.device)))
+        self._call("az_engine_get_positions", self.h, _host_ptr(white), _host_ptr(black),
+                                                 _host_ptr(turn), _host_ptr(winner), _stream(self.device))
         return white, black, turn, winner
 
     def set_active(self, active):
         a = np.ascontiguousarray(active, np.uint8)
         assert a.shape == (self.n,)
-        with torch.cuda.device(self.device):
-            check(_lib.lib().az_engine_set_active(self.h, _host_ptr(a), _stream(self.device)))
+        self._call("az_engine_set_active", self.h, _host_ptr(a), _stream(self.device))
 
     # ------------------------------------------------------------ search steps
     def roots_prepare(self):
-        check(_lib.lib().az_engine_roots_prepare(self.h, _dev_ptr(self.planes), _dev_ptr(self.need), _stream(self.device)))
+        self._call("az_engine_roots_prepare", self.h, _dev_ptr(self.planes), _dev_ptr(self.need), _stream(self.device))
 
     def roots_expand(self, probs):
         assert probs.is_cuda and probs.dtype == torch.float32 and probs.shape == (self.n, 192) and probs.is_contiguous()
-        check(_lib.lib().az_engine_roots_expand(self.h, _dev_ptr(probs), _stream(self.device)))
+        self._call("az_engine_roots_expand", self.h, _dev_ptr(probs), _stream(self.device))
 
     def add_noise(self, noise=None):
         """noise: [n,48] float64 Dirichlet draws (host array or cuda tensor) or None
@@ -140,15 +140,15 @@ class Engine:
             noise = torch.from_numpy(np.ascontiguousarray(noise, np.float64)).to(self.device)
         if noise is not None:
             assert noise.dtype == torch.float64 and noise.shape == (self.n, 48) and noise.is_contiguous()
-        check(_lib.lib().az_engine_add_noise(self.h, _dev_ptr(noise), _stream(self.device)))
+        self._call("az_engine_add_noise", self.h, _dev_ptr(noise), _stream(self.device))
 
     def select(self):
-        check(_lib.lib().az_engine_select(self.h, _dev_ptr(self.planes), _dev_ptr(self.need), _stream(self.device)))
+        self._call("az_engine_select", self.h, _dev_ptr(self.planes), _dev_ptr(self.need), _stream(self.device))
 
     def expand_backup(self, probs, values):
         assert probs.is_cuda and probs.dtype == torch.float32 and probs.shape == (self.n, 192) and probs.is_contiguous()
         assert values.is_cuda and values.dtype == torch.float32 and values.shape == (self.n,) and values.is_contiguous()
-        check(_lib.lib().az_engine_expand_backup(self.h, _dev_ptr(probs), _dev_ptr(values), _stream(self.device)))
+        self._call("az_engine_expand_backup", self.h, _dev_ptr(probs), _dev_ptr(values), _stream(self.device))
 
     # ------------------------------------------------------------ queries
     def node_children(self, g, node=-1):
@@ -162,11 +162,10 @@ class Engine:
         nN = C.c_uint32()
         nW = C.c_float()
         nidx = C.c_int64()
-        with torch.cuda.device(self.device):
-            check(_lib.lib().az_engine_node_children(
-                self.h, int(g), int(node), C.byref(k), _host_ptr(act), _host_ptr(N), _host_ptr(W),
-                _host_ptr(P), _host_ptr(is64), _host_ptr(idx), C.byref(nN), C.byref(nW),
-                C.byref(nidx), _stream(self.device)))
+        self._call("az_engine_node_children",
+            self.h, int(g), int(node), C.byref(k), _host_ptr(act), _host_ptr(N), _host_ptr(W),
+            _host_ptr(P), _host_ptr(is64), _host_ptr(idx), C.byref(nN), C.byref(nW),
+            C.byref(nidx), _stream(self.device))
         if k.value < 0:
             return None
         kk = k.value
@@ -189,11 +188,10 @@ class Engine:
         nN = np.zeros(n, np.uint32)
         nW = np.zeros(n, np.float32)
         nidx = np.zeros(n, np.int64)
-        with torch.cuda.device(self.device):
-            check(_lib.lib().az_engine_roots_children(
-                self.h, n, _host_ptr(slots), _host_ptr(k), _host_ptr(act), _host_ptr(N), _host_ptr(W),
-                _host_ptr(P), _host_ptr(is64), _host_ptr(idx), _host_ptr(nN), _host_ptr(nW), _host_ptr(nidx),
-                _stream(self.device)))
+        self._call("az_engine_roots_children",
+            self.h, n, _host_ptr(slots), _host_ptr(k), _host_ptr(act), _host_ptr(N), _host_ptr(W),
+            _host_ptr(P), _host_ptr(is64), _host_ptr(idx), _host_ptr(nN), _host_ptr(nW), _host_ptr(nidx),
+            _stream(self.device))
         out = []
         for i in range(n):
             kk = int(k[i])
@@ -208,35 +206,32 @@ class Engine:
     def action_probs_all(self, temps=None, out=None):
         out = self.probs if out is None else out
         t = None if temps is None else np.ascontiguousarray(temps, np.float32)
-        check(_lib.lib().az_engine_action_probs(self.h, _host_ptr(t), _dev_ptr(out), _stream(self.device)))
+        self._call("az_engine_action_probs", self.h, _host_ptr(t), _dev_ptr(out), _stream(self.device))
         return out
 
     def advance_all(self, actions):
         a = np.ascontiguousarray(actions, np.int16)
         assert a.shape == (self.n,)
-        with torch.cuda.device(self.device):
-            check(_lib.lib().az_engine_advance(self.h, _host_ptr(a), _stream(self.device)))
+        self._call("az_engine_advance", self.h, _host_ptr(a), _stream(self.device))
 
     def set_root(self, g, node):
-        check(_lib.lib().az_engine_set_root(self.h, int(g), int(node), _stream(self.device)))
+        self._call("az_engine_set_root", self.h, int(g), int(node), _stream(self.device))
 
     def set_roots(self, slots, nodes):
         """Re-root several games in one launch (slots[i] at pool node nodes[i])."""
         slots = np.ascontiguousarray(slots, np.int32)
         nodes = np.ascontiguousarray(nodes, np.int64)
         assert len(slots) == len(nodes)
-        with torch.cuda.device(self.device):
-            check(_lib.lib().az_engine_set_roots(self.h, len(slots), _host_ptr(slots), _host_ptr(nodes), _stream(self.device)))
+        self._call("az_engine_set_roots", self.h, len(slots), _host_ptr(slots), _host_ptr(nodes), _stream(self.device))
 
     def pool_usage(self):
         used = np.zeros(self.n, np.uint32)
-        with torch.cuda.device(self.device):
-            check(_lib.lib().az_engine_pool_usage(self.h, _host_ptr(used), _stream(self.device)))
+        self._call("az_engine_pool_usage", self.h, _host_ptr(used), _stream(self.device))
         return used
 
     def mean_depth(self):
         d, n = C.c_uint64(), C.c_uint64()
-        check(_lib.lib().az_engine_stats(self.h, C.byref(d), C.byref(n), _stream(self.device)))
+        self._call("az_engine_stats", self.h, C.byref(d), C.byref(n), _stream(self.device))
         return d.value / max(1, n.value)
 
     # ------------------------------------------------------------ one search_batch
@@ -260,25 +255,25 @@ class Engine:
     # ------------------------------------------------------------ fused self-play
     def attach_net(self, inference):
         """inference: alphazero_amd.model.HipInference with max_batch >= n_games."""
-        check(_lib.lib().az_engine_attach_net(self.h, inference.h))
+        self._call("az_engine_attach_net", self.h, inference.h)
         self.net = inference
 
     def search(self, num_simulations, add_noise=False):
-        check(_lib.lib().az_engine_search(self.h, int(num_simulations), int(bool(add_noise)), _stream(self.device)))
+        self._call("az_engine_search", self.h, int(num_simulations), int(bool(add_noise)), _stream(self.device))
 
     def play_move(self, num_simulations, add_noise=True, actions=None, restart_finished=True):
         a = None if actions is None else np.ascontiguousarray(actions, np.int16)
-        check(_lib.lib().az_engine_play_move(self.h, int(num_simulations), int(bool(add_noise)),
-                                             _host_ptr(a), int(bool(restart_finished)), _stream(self.device)))
+        self._call("az_engine_play_move", self.h, int(num_simulations), int(bool(add_noise)),
+                                             _host_ptr(a), int(bool(restart_finished)), _stream(self.device))
 
     def chosen_actions(self):
         a = np.zeros(self.n, np.int16)
-        check(_lib.lib().az_engine_chosen_actions(self.h, _host_ptr(a), _stream(self.device)))
+        self._call("az_engine_chosen_actions", self.h, _host_ptr(a), _stream(self.device))
         return a
 
     def samples_pending(self):
         n = C.c_int64()
-        check(_lib.lib().az_engine_drain_samples(self.h, 0, None, None, None, C.byref(n), _stream(self.device)))
+        self._call("az_engine_drain_samples", self.h, 0, None, None, None, C.byref(n), _stream(self.device))
         return n.value
 
     def drain_samples(self):
@@ -289,8 +284,8 @@ class Engine:
         wls = torch.empty((n, 2), dtype=torch.float32, device=self.device)
         if n:
             got = C.c_int64()
-            check(_lib.lib().az_engine_drain_samples(self.h, n, _dev_ptr(states), _dev_ptr(policies),
-                                                     _dev_ptr(wls), C.byref(got), _stream(self.device)))
+            self._call("az_engine_drain_samples", self.h, n, _dev_ptr(states), _dev_ptr(policies),
+                                                     _dev_ptr(wls), C.byref(got), _stream(self.device))
             assert got.value == n
         return states, policies, wls
 
@@ -301,14 +296,13 @@ class Engine:
         packed = torch.empty((n, _lib.PACKED_SAMPLE_BYTES), dtype=torch.uint8, device=self.device)
         if n:
             got = C.c_int64()
-            with torch.cuda.device(self.device):
-                check(_lib.lib().az_engine_drain_packed(self.h, n, _dev_ptr(packed), C.byref(got), _stream(self.device)))
+            self._call("az_engine_drain_packed", self.h, n, _dev_ptr(packed), C.byref(got), _stream(self.device))
             assert got.value == n
         return packed
 
     def stats(self):
         st = _lib.SelfplayStats()
-        check(_lib.lib().az_engine_selfplay_stats(self.h, C.byref(st), _stream(self.device)))
+        self._call("az_engine_selfplay_stats", self.h, C.byref(st), _stream(self.device))
         return dict(simulations=st.simulations, nn_evals=st.nn_evals, moves=st.moves,
                     games_finished=st.games_finished, samples_pending=st.samples_pending,
                     network_rows=st.network_rows)

@@ -208,8 +208,11 @@ class MCTS:
             dev = torch.device(self.device) if str(self.device).startswith("cuda") else None
             self._pool = _SlotPool(self.c_puct, device=None if dev is None else dev.index)
         # bind every game to a device tree
-        fresh = [i for i in range(n) if not (isinstance(roots[i], Node) and roots[i]._tree is not None
-                                             and roots[i]._tree.pool is self._pool)]
+        for r in roots:
+            if isinstance(r, Node) and r._tree is not None and r._tree.pool is not self._pool:
+                raise _lib.AzError("this root belongs to a tree built by another MCTS object: search it with that "
+                                   "object, or pass root=None to start a fresh tree")
+        fresh = [i for i in range(n) if not (isinstance(roots[i], Node) and roots[i]._tree is not None)]
         for i in fresh:
             r = roots[i]
             if r is not None and r._tree is None and len(r._children or {}) > 0:
@@ -223,9 +226,29 @@ class MCTS:
         by_engine: Dict[int, List[int]] = {}
         for i in range(n):
             by_engine.setdefault(id(roots[i]._tree.engine), []).append(i)
-        for idxs in by_engine.values():
-            self._search_on_engine(roots[idxs[0]]._tree.engine, [games[i] for i in idxs],
-                                   [roots[i] for i in idxs], add_noise)
+        groups = [(roots[idxs[0]]._tree.engine, idxs) for idxs in by_engine.values()]
+        try:
+            # 1. positions up, re-roots, missing roots expanded - engine by engine
+            for engine, idxs in groups:
+                self._prepare_on_engine(engine, [games[i] for i in idxs], [roots[i] for i in idxs])
+            # 2. one np.random.dirichlet draw per expanded root in ROOT-INDEX order, whatever engine a
+            #    root lives on: the draws of the global numpy generator are consumed exactly as
+            #    the reference consumes them (src/mcts.py:141-144, 322)
+            noise = None
+            if add_noise:
+                counts = {id(engine): engine.root_counts() for engine, _ in groups}
+                noise = {id(engine): np.zeros((engine.n, 48), np.float64) for engine, _ in groups}
+                for i in range(n):
+                    t = roots[i]._tree
+                    k = int(counts[id(t.engine)][t.slot])
+                    if k > 0:
+                        noise[id(t.engine)][t.slot, :k] = np.random.dirichlet([Config.DIRICHLET_ALPHA] * k)
+            # 3. the simulations, engine by engine
+            for engine, idxs in groups:
+                self._simulate_on_engine(engine, [roots[i] for i in idxs], None if noise is None else noise[id(engine)])
+        finally:
+            for engine, _ in groups:                 # also after an error: no game stays active
+                engine.set_active(np.zeros(engine.n, np.uint8))
         return roots
 
     def get_action_probs(self, root: Node, temperature: float = 1.0) -> np.ndarray:
@@ -281,7 +304,8 @@ class MCTS:
         engine.values.index_copy_(0, rows, values.to(engine.device, torch.float32))
         return engine.probs, engine.values
 
-    def _search_on_engine(self, engine, games, roots, add_noise):
+    def _prepare_on_engine(self, engine, games, roots):
+        """Positions up, reused trees re-rooted at the node passed in, missing roots expanded."""
         slots = np.array([r._tree.slot for r in roots], np.int32)
         wb = [board_to_bits(g.board) for g in games]
         white = np.array([x[0] for x in wb], dtype=np.uint64)
@@ -319,13 +343,14 @@ class MCTS:
             engine.roots_prepare()
             probs, _ = self._evaluate(engine, engine.planes, engine.need)
             engine.roots_expand(probs)
-        if add_noise:
-            # one np.random.dirichlet draw per expanded root, in order (src/mcts.py:141-144, 322)
-            k = engine.root_counts()
-            noise = np.zeros((engine.n, 48), np.float64)
-            for s in slots:
-                if k[s] > 0:
-                    noise[s, :k[s]] = np.random.dirichlet([Config.DIRICHLET_ALPHA] * int(k[s]))
+
+    def _simulate_on_engine(self, engine, roots, noise):
+        slots = np.array([r._tree.slot for r in roots], np.int32)
+        active = np.zeros(engine.n, np.uint8)
+        active[slots] = 1
+        engine.set_active(active)
+        hip = self._hip_inference(engine)
+        if noise is not None:
             engine.add_noise(noise)
         if hip is not None:
             engine.search(self.num_simulations, add_noise=False)
@@ -334,7 +359,7 @@ class MCTS:
                 engine.select()
                 probs, values = self._evaluate(engine, engine.planes, engine.need)
                 engine.expand_backup(probs, values)
-        engine.pool_usage()                   # surfaces a sticky capacity error
+        engine.pool_usage()                   # reports a capacity error of this search
         engine.set_active(np.zeros(engine.n, np.uint8))
         # every returned root is read next (visit counts, children): one launch and one copy
         # for all of them instead of one per handle

@@ -75,7 +75,9 @@ int az_net_max_batch(az_net* n);
  * (src/model.py:123-142), flattened and concatenated in state_dict order
  * (num_batches_tracked entries skipped), float32, `count` floats in total.
  * BatchNorm is folded (eval mode) and the weights are re-laid-out for the MFMA
- * kernels here; call again after every training step that changes the weights. */
+ * kernels here; call again after every training step that changes the weights.
+ * Synchronises the device first (forwards still running on any stream keep the old
+ * weights) and returns with the new ones in place. */
 int az_net_load_state(az_net* n, const float* state_host, int64_t count);
 /* mine_dev / theirs_dev [B] u64 canonical bitboards (planes 0 and 1 of
  * src/game.py:280-307; plane 2 is implicit).  Outputs: probs_dev [B][192]
@@ -206,7 +208,9 @@ int az_engine_root_counts(az_engine* e, int32_t* counts_host, void* stream);
 /* MCTS.get_action_probs (src/mcts.py:191-225) for every active game, with the
  * temperature schedule of src/parallel_trainer.py:164 when temps_host is NULL
  * (1.0 while the game's ply count < temperature_threshold, else 0), or the
- * given per-game temperatures (each must be 0 or 1).  probs_dev [B][192] f32. */
+ * given per-game temperatures (>= 0).  Temperatures 0 and 1 reproduce the reference bit for
+ * bit; any other one evaluates count ** (1 / T) / sum in float32 on the device and equals
+ * numpy's result within rounding (relative 1e-5).  probs_dev [B][192] f32. */
 int az_engine_action_probs(az_engine* e, const float* temps_host, float* probs_dev, void* stream);
 
 /* src/parallel_trainer.py:190-198: play action actions_host[g] (< 0: leave the

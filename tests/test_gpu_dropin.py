@@ -194,3 +194,58 @@ def test_arena_game_through_the_dropin_equals_the_reference_game(golden_dir):
     assert game.is_terminal()
     assert tuple(np.float32(x) for x in game.get_result()) == tuple(d["game_result"])
     assert tuple(int(x) for x in board_to_bits(game.board)) == tuple(int(x) for x in d["game_final"])
+
+
+def test_noise_draws_follow_root_order_across_engines(golden_dir, monkeypatch):
+    """The reference draws one np.random.dirichlet vector per root in root-index order
+    (src/mcts.py:141-144).  With the roots of one search_batch spread over two engines in an
+    interleaved pattern the drop-in must still consume the global generator in that order:
+    the recorded noisy tree-reuse sequence comes out bit for bit."""
+    from alphazero_amd.mcts import Node, _SlotPool, _Tree
+    d = np.load(os.path.join(golden_dir, "tree_tier.npz"))
+    sel = d["noisy_games"]
+    m = _table_mcts(int(d["noisy_sims"]))
+    pool = m._pool = _SlotPool(m.c_puct, capacity=2)
+    a = pool.acquire(2)                    # engine A, both slots
+    b = pool.acquire(2)                    # engine B, both slots
+    assert a[0][0] is a[1][0] and b[0][0] is b[1][0] and a[0][0] is not b[0][0]
+    placement = [b[0], a[0], b[1], a[1]]   # games 0 and 2 on engine B, games 1 and 3 on engine A
+    games = [_game(d["white"][g], d["black"][g], d["turn"][g]) for g in sel]
+    roots = []
+    for eng, slot in placement:
+        r = Node(0)
+        r._bind(_Tree(pool, eng, slot), -1)
+        roots.append(r)
+    draws = []
+
+    def replay(alpha, *args, **kw):
+        ply, i = draws[0]
+        draws.pop(0)
+        return d["noisy_noise"][ply, i][:len(alpha)]
+    monkeypatch.setattr(np.random, "dirichlet", replay)
+    alive = list(range(len(games)))
+    for ply in range(d["noisy_played"].shape[0]):
+        if not alive:
+            break
+        draws[:] = [(ply, i) for i in alive]                 # the order the reference drew them in
+        new = m.search_batch([games[i] for i in alive], [roots[i] for i in alive], add_noise=True)
+        assert not draws
+        for j, i in enumerate(alive):
+            roots[i] = new[j]
+        for i in list(alive):
+            _check_children(_stats(roots[i]), d, "noisy", (ply, i))
+            act = int(d["noisy_played"][ply, i])
+            games[i].step(games[i].decode_action(act))
+            roots[i] = roots[i].children[act] if act in roots[i].children else None
+            if games[i].is_terminal():
+                alive.remove(i)
+
+
+def test_a_root_of_another_mcts_object_is_refused():
+    from alphazero_amd._lib import AzError
+    from alphazero_amd.game import BreakthroughGame
+    one, two = _table_mcts(4), _table_mcts(4)
+    root = one.search(BreakthroughGame())
+    with pytest.raises(AzError, match="another MCTS object"):
+        two.search(BreakthroughGame(), root=root)
+    assert two.search(BreakthroughGame()).visit_count == 4   # and the object still works

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import oracle as orc
 from test_gpu_dropin import _table_mcts
 
 pytestmark = pytest.mark.gpu
@@ -171,3 +172,49 @@ def test_examples_stay_on_the_device_from_the_queue_to_the_optimiser(tmp_path, m
     view = tr.examples                                              # now the host view is built, once
     assert view.states.shape == (len(ex), 3, 8, 8) and np.array_equal(view.policies, ex.policies)
     assert tr.examples is view
+
+
+def test_one_game_100_sims_full_network_against_the_oracle(tmp_path, monkeypatch):
+    """The plumbing configuration (1 self-play game x 100 simulations per move, SE-ResNet 20 x 128,
+    root noise, temperature schedule, tree reuse, played to the end) through the drop-in trainer's
+    reference loop on the HIP path, against the CPU oracle driven by the same network's outputs and
+    the same numpy draws: every (state, pi, wl) example equal bit for bit."""
+    from selfplay_replay import replay_selfplay_oracle
+    from alphazero_amd.model import AlphaZeroNet, HipInference
+    from alphazero_amd.parallel_trainer import ParallelTrainer
+    torch.manual_seed(0)
+    model = AlphaZeroNet(num_blocks=20, num_filters=128).cuda().eval()
+    tr = ParallelTrainer(model, device="cuda", num_parallel_games=1, num_simulations=100,
+                         checkpoint_dir=str(tmp_path), verbose=False)
+    dirichlet, choices = [], []
+    real_dirichlet, real_choice = np.random.dirichlet, np.random.choice
+
+    def rec_dirichlet(alpha, *a, **k):
+        v = real_dirichlet(alpha, *a, **k)
+        dirichlet.append(np.concatenate([v, np.zeros(48 - len(v))]))
+        return v
+
+    def rec_choice(n, *a, **k):
+        v = real_choice(n, *a, **k)
+        choices.append(int(v))
+        return v
+    monkeypatch.setattr(np.random, "dirichlet", rec_dirichlet)
+    monkeypatch.setattr(np.random, "choice", rec_choice)
+    np.random.seed(0)
+    ex = tr._host_loop_episodes(1)                      # the reference's loop over the drop-in MCTS
+    monkeypatch.undo()
+    assert tr.mcts._hip is not None                     # the searches ran on the HIP network
+    assert len(ex) == len(choices) >= 20 and np.all(ex.wls.sum(1) == 1.0)
+
+    inf = HipInference(model, max_batch=16)
+    start = orc.encode_state(orc.start_position())
+
+    def evaluate(planes, need):
+        x = np.ascontiguousarray(planes, np.float32).copy()
+        x[np.asarray(need) == 0] = start
+        probs, value, _, _ = inf.forward_planes(torch.from_numpy(x).cuda())
+        return probs.cpu().numpy().copy(), value.cpu().numpy().copy()
+    s, p, w = replay_selfplay_oracle(1, 100, np.array(dirichlet), np.array(choices), evaluate)
+    assert np.array_equal(ex.states, np.stack(s))
+    assert np.array_equal(ex.policies.view(np.uint32), np.stack(p).view(np.uint32))
+    assert np.array_equal(ex.wls, np.stack(w))

@@ -189,3 +189,39 @@ def test_deep_reuse_matches_reference(golden_dir):
     d = np.load(os.path.join(golden_dir, "tree_deep_tier.npz"))
     checked, top = replay_deep_tier(EngineBackend(len(d["white"]), pool_nodes_per_game=1 << 16), d)
     assert checked == int((d["played"] != 255).sum()) and top > 1500
+
+
+def test_action_probs_at_any_temperature(golden_dir):
+    """get_action_probs (src/mcts.py:191-225) on the device for the temperatures of
+    tests/golden/probs_tier (0, 0.25, 0.5, 1, 2) on searched roots: 0 and 1 bit for bit,
+    the others against the reference's own formula evaluated with numpy (np.power, sum,
+    divide in float32) within relative 1e-5."""
+    from fake_net import TableEvaluator
+    from gpu_backend import EngineBackend
+    d = np.load(os.path.join(golden_dir, "tree_wide_tier.npz"))
+    nG = len(d["white"])
+    dev = EngineBackend(nG, pool_nodes_per_game=1 << 14)
+    for g in range(nG):
+        dev.set_game(g, orc.make_pos(d["white"][g], d["black"][g], d["turn"][g]))
+    dev.search(TableEvaluator(), 200)
+    temps_cycle = [0.0, 0.25, 0.5, 1.0, 2.0]
+    temps = np.array([temps_cycle[g % 5] for g in range(nG)], np.float32)
+    got = dev.e.action_probs_all(temps).cpu().numpy()
+    for g in range(nG):
+        q = dev.root_children(g)
+        assert np.array_equal(q["N"], d["plain_N"][g][: len(q["N"])])
+        want = np.zeros(192, np.float32)
+        want[q["actions"]] = q["N"]
+        T = float(temps[g])
+        if T == 0:
+            best = int(np.argmax(want))
+            want = np.zeros(192, np.float32)
+            want[best] = 1.0
+        else:
+            want = np.power(want, 1.0 / T)
+            want /= want.sum()
+        if T in (0.0, 1.0):
+            assert np.array_equal(got[g].view(np.uint32), want.view(np.uint32)), (g, T)
+        else:
+            np.testing.assert_allclose(got[g], want, rtol=1e-5, atol=1e-9)
+            assert np.count_nonzero(got[g]) == np.count_nonzero(want)
