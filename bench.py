@@ -315,10 +315,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        limit = datetime.timedelta(seconds=300)    # a rank that died must not leave the others waiting for ever
         if rehearsal:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=limit)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=limit)
 
     from alphazero_amd.model import AlphaZeroNet
     from alphazero_amd.selfplay import SelfPlay
