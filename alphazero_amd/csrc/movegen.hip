@@ -123,10 +123,12 @@ extern "C" int az_movegen_encode(int64_t n, const uint64_t* white_dev, const uin
                      ((uintptr_t)legal3_dev & 7) == 0,
                  "az_movegen_encode: planes and mask must be 16-byte aligned, legal3 8-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    const int64_t groups = (n + 63) / 64;  // one wave per 64 positions
+    // One wave per 64 positions and one pass per wave: a grid capped at a few workgroups per CU
+    // with a grid-stride loop in the kernel measured 18 % slower from HBM (4.87 against
+    // 5.93 TB/s at 64 M positions); the loop only serves inputs beyond the grid limit.
+    const int64_t groups = (n + 63) / 64;
     int64_t blocks = (groups + 3) / 4;
-    const bool heavy = mask192_dev || planes_dev;
-    const int64_t cap = heavy ? 256 * 32 : 256 * 8;
+    const int64_t cap = 0x7FFFFFFF;
     if (blocks > cap) blocks = cap;
     dim3 grid((unsigned)blocks), block(256);
     if (mask192_dev && planes_dev)

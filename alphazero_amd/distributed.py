@@ -122,9 +122,12 @@ def sync_batchnorm_buffers(model: torch.nn.Module, weight: float, group=None):
         for b in floats:
             b.mul_(weight)
         _flat_allreduce(floats, group)
-    for b in model.buffers():
-        if not b.is_floating_point():
-            dist.all_reduce(b, op=dist.ReduceOp.MAX, group=group)
+    counters = [b for b in model.buffers() if not b.is_floating_point()]
+    if counters:                                   # one collective for all of them
+        flat = torch.stack([b.reshape(()).to(torch.int64) for b in counters])
+        dist.all_reduce(flat, op=dist.ReduceOp.MAX, group=group)
+        for b, v in zip(counters, flat.unbind(0)):
+            b.copy_(v)
 
 
 def losses(model, states, target_pis, target_wls):
