@@ -417,3 +417,41 @@ def test_fused_search_with_more_games_than_one_scan_pass(small_model):
         assert np.array_equal(a["W"].view(np.uint32), o["W"].view(np.uint32))
     st = fused.stats()
     assert st["network_rows"] == st["nn_evals"]
+
+
+def test_sample_queue_order_with_more_games_than_one_scan_pass(small_model):
+    """1,100 games (the finish scan handles 1,024 per pass) played to the end with device-drawn
+    moves: the drained samples must come ply by ply and, within a ply, by ascending game index,
+    each finished game contributing its whole history in move order with the right wl sign -
+    checked against positions replayed on the host from the moves the engine reports."""
+    from alphazero_amd.selfplay import SelfPlay
+    nG = 1100
+    sp = SelfPlay(small_model, n_games=nG, num_simulations=1, seed=12, pool_nodes_per_game=256)
+    e = sp.engine
+    e.reset_all()
+    e.set_active(np.ones(nG, np.uint8))
+    pos = [orc.start_position() for _ in range(nG)]
+    hist = [[] for _ in range(nG)]
+    alive = np.ones(nG, bool)
+    want_states, want_wl = [], []
+    for _ in range(300):
+        if not alive.any():
+            break
+        e.play_move(1, add_noise=True, restart_finished=False)
+        acts = e.chosen_actions()
+        for g in np.flatnonzero(alive):
+            assert acts[g] >= 0
+            hist[g].append((orc.encode_state(pos[g]), pos[g].turn))
+            pos[g] = orc.step_action(pos[g], int(acts[g]))
+            if orc.is_terminal(pos[g]):
+                w, l = orc.get_result(pos[g])
+                for s, turn in hist[g]:
+                    want_states.append(s)
+                    want_wl.append((w, l) if turn == 1 else (l, w))
+                alive[g] = False
+    assert not alive.any()
+    s, p, wl = [x.cpu().numpy() for x in e.drain_samples()]
+    assert len(s) == len(want_states) == e.stats()["moves"]
+    assert np.array_equal(s, np.stack(want_states))
+    assert np.array_equal(wl, np.array(want_wl, np.float32))
+    assert np.allclose(p.sum(1), 1.0, atol=1e-5)
