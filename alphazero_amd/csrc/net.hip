@@ -1655,6 +1655,12 @@ static int forward_partial(az_net* n, int32_t B, const uint64_t* mine_dev, const
     AZ_CHECK_ARG(n && n->loaded, "az_net_forward: network has no weights (call az_net_load_state)");
     if (B == 0) return AZ_OK;
     AZ_CHECK_ARG(mine_dev && theirs_dev, "az_net_forward: null pointer");
+    // kernels run on the calling thread's current device; the weights and head buffers (the
+    // static ones included) live on the network's: launching across the two would fault
+    int current = -1;
+    AZ_HIP(hipGetDevice(&current));
+    if (current != n->device)
+        AZ_FAIL(AZ_ERR_STATE, "az_net_forward: the network lives on device %d but device %d is current", n->device, current);
     TowerParams tp;
     tp.mine = mine_dev; tp.theirs = theirs_dev; tp.B = B; tp.blocks = n->blocks;
     tp.need = nullptr; tp.n_games = 0; tp.row_of = nullptr; tp.n_rows = nullptr; tp.rows_total = nullptr;

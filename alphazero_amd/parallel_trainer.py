@@ -195,11 +195,12 @@ class ReplayRing:
         return (logical + self.start) % self.rows if self.start else logical
 
     def ordered(self) -> ExampleArrays:
-        """The contents, oldest first (views of the storage when it has not wrapped)."""
+        """A copy of the contents, oldest first (on the ring's device; later appends do not
+        reach into it)."""
         if self.n == 0:
             return ExampleArrays()
         if self.start == 0:
-            return ExampleArrays(self.s[:self.n], self.p[:self.n], self.w[:self.n])
+            return ExampleArrays(self.s[:self.n].clone(), self.p[:self.n].clone(), self.w[:self.n].clone())
         idx = self.physical(torch.arange(self.n, device=self.device))
         return ExampleArrays(self.s[idx], self.p[idx], self.w[idx])
 
