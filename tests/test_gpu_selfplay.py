@@ -455,3 +455,22 @@ def test_sample_queue_order_with_more_games_than_one_scan_pass(small_model):
     assert np.array_equal(s, np.stack(want_states))
     assert np.array_equal(wl, np.array(want_wl, np.float32))
     assert np.allclose(p.sum(1), 1.0, atol=1e-5)
+
+
+def test_exchange_steps_run_over_rccl_with_one_rank():
+    """The exchange code over the real RCCL backend (backend "nccl"), world of one rank: the
+    collectives' dtypes and call forms are ones RCCL takes.  Own process: a process group is
+    process-wide state."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(here, "nccl_single_rank.py"), str(port)], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (r.stdout[-500:], r.stderr[-3000:])
