@@ -109,7 +109,7 @@ struct Rng {
 
 enum Phase { PHASE_IDLE = 0, PHASE_ROOTS = 1, PHASE_SELECTED = 2 };
 
-// k_finish_scan's verdict on a game after a move
+// what k_finish_scan found for a game after a move
 constexpr int FIN_NONE = 0, FIN_BLACK = 1, FIN_WHITE = 2, FIN_DROPPED = 4;  // DROPPED: queue full
 
 constexpr int MAX_PLIES = 256;  // per-game history depth (a game lasts < 200 plies)

@@ -14,7 +14,7 @@ Outputs (all data, no code):
     nn_tier.npz      float32 logits of seeded AlphaZeroNet instances
     latency_tier.npz   MCTS.search(game, add_noise=False) with a fresh root at 200 simulations, the
                      move arena.py / web.py pick from it, and one whole arena-style game
-    baseline_movegen_tier.npz  legal-move sets and terminal verdicts of the reference's second,
+    baseline_movegen_tier.npz  legal-move sets and terminal results of the reference's second,
                      independently written move generator (src/baseline/state.py)
 """
 import os
