@@ -258,7 +258,10 @@ int az_engine_search(az_engine* e, int32_t num_simulations, int32_t add_noise, v
  * record (state, pi, turn), choose the move (actions_host[g] if given, else a
  * device draw from pi), step + re-root, and for finished games emit their
  * samples into the queue and restart them (restart_finished != 0) or drop them
- * from the active set. */
+ * from the active set.  Samples are queued in the reference's order: move by move,
+ * within a move by ascending game index, within a game by ply
+ * (src/parallel_trainer.py:176-217); a game that does not fit the queue is dropped
+ * whole and reported as AZ_ERR_CAPACITY. */
 int az_engine_play_move(az_engine* e, int32_t num_simulations, int32_t add_noise,
                         const int16_t* actions_host, int32_t restart_finished, void* stream);
 int az_engine_chosen_actions(az_engine* e, int16_t* actions_host, void* stream);
