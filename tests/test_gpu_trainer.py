@@ -218,3 +218,39 @@ def test_one_game_100_sims_full_network_against_the_oracle(tmp_path, monkeypatch
     assert np.array_equal(ex.states, np.stack(s))
     assert np.array_equal(ex.policies.view(np.uint32), np.stack(p).view(np.uint32))
     assert np.array_equal(ex.wls, np.stack(w))
+
+
+def test_one_iteration_of_the_reference_training_loop(tmp_path):
+    """The body of the reference's main.train loop (main.py:66-90), statement for statement, on the
+    drop-in trainer with the fused device self-play: several self-play batches collected into a
+    Python list and into the replay buffer, learn(), the data file, the iteration checkpoint,
+    and the restart path (get_latest_iteration / load_iteration_checkpoint / load_training_data,
+    main.py:54-59)."""
+    from alphazero_amd.model import AlphaZeroNet
+    from alphazero_amd.parallel_trainer import ParallelTrainer
+    torch.manual_seed(3)
+    model = AlphaZeroNet(num_blocks=1, num_filters=128).to("cuda")
+    trainer = ParallelTrainer(model, device="cuda", num_parallel_games=8, num_simulations=8,
+                              checkpoint_dir=str(tmp_path), seed=1, verbose=False)
+    all_new_examples = []
+    for _ in range(2):
+        new_examples = trainer.execute_parallel_episodes(num_games=8)
+        all_new_examples.extend(new_examples)
+        trainer.add_examples(new_examples)
+    assert len(all_new_examples) == len(trainer.examples) >= 2 * 8 * 10
+    state, policy, wl = all_new_examples[0]
+    assert state.shape == (3, 8, 8) and policy.shape == (192,) and wl.shape == (2,)
+    stats = trainer.learn(epochs=1, batch_size=64)
+    assert np.isfinite(stats["loss"])
+    trainer.append_training_data(all_new_examples)
+    trainer.save_iteration_checkpoint(1)
+    # restart
+    torch.manual_seed(4)
+    again = ParallelTrainer(AlphaZeroNet(num_blocks=1, num_filters=128).to("cuda"), device="cuda", num_parallel_games=8,
+                            num_simulations=8, checkpoint_dir=str(tmp_path), seed=1, verbose=False)
+    assert again.get_latest_iteration() == 1 and again.load_iteration_checkpoint(1)
+    assert again.load_training_data() == len(all_new_examples)
+    for a, b in zip(model.state_dict().values(), again.model.state_dict().values()):
+        assert torch.equal(a, b)
+    assert np.array_equal(again.examples.policies, trainer.examples.policies)
+    assert len(again.execute_parallel_episodes(num_games=4)) >= 4 * 10    # and it plays on with the restored weights
