@@ -52,7 +52,7 @@ def one_round(seed, max_batch=1100, verbose=False):
     rs = np.random.RandomState(seed)
     blocks = int(rs.choice([1, 2, 3, 5, 8]))
     B = int(rs.choice([1, 2, 3, 4, 5, 15, 16, 17, 255, 256, 257, 511, 512, 513, int(rs.randint(1, max_batch))]))
-    form = int(rs.choice([0, 1, 2, 4, 8]))
+    form = int(rs.choice([0, 1, 2, 4, 8, 16]))
     model = _random_model(rs, blocks)
     w, b, t, _ = orc.random_positions(B, seed)
     _, _, planes, _ = orc.movegen_batch(w, b, t, want_mask=False)

@@ -134,7 +134,7 @@ def test_forward_is_reproducible_from_the_first_call(B):
 
 
 def test_every_tower_form_computes_the_same_network():
-    """Forms 1, 2, 4 and 8 of the tower on one batch: each within tolerance of the float32
+    """Forms 1, 2, 4, 8 and 16 of the tower on one batch: each within tolerance of the float32
     torch forward, equal to one another up to summation order, and bit-reproducible."""
     from alphazero_amd.model import AlphaZeroNet, HipInference
     torch.manual_seed(2)
@@ -150,7 +150,7 @@ def test_every_tower_form_computes_the_same_network():
     value_ref = wlp[:, 0] - wlp[:, 1]
     inf = HipInference(model, max_batch=304)
     out = {}
-    for form in (1, 2, 4, 8):
+    for form in (1, 2, 4, 8, 16):
         inf.set_tower_form(form)
         p, v, _, _ = inf.forward_planes(x.cuda())
         p, v = p.clone(), v.clone()
@@ -159,7 +159,7 @@ def test_every_tower_form_computes_the_same_network():
             assert torch.equal(p2, p) and torch.equal(v2, v), form
         out[form] = (p.cpu().numpy(), v.cpu().numpy())
         assert np.abs(out[form][0] - probs_ref).max() <= TOL and np.abs(out[form][1] - value_ref).max() <= TOL
-    for form in (1, 2, 8):
+    for form in (1, 2, 8, 16):
         assert np.abs(out[form][0] - out[4][0]).max() < 1e-3, form
         assert np.abs(out[form][1] - out[4][1]).max() < 1e-2, form
     inf.set_tower_form(0)
