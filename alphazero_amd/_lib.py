@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libazamd.so")
+LIB_PATH = os.environ.get("AZAMD_LIB") or os.path.join(_HERE, "libazamd.so")   # AZAMD_LIB: a diagnostic build of the same library
 
 
 class AzError(RuntimeError):

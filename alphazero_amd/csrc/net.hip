@@ -1472,15 +1472,17 @@ static int forward_partial(az_net* n, int32_t B, const uint64_t* mine_dev, const
     tp.value_w = n->value_w; tp.value_b = n->value_b; tp.p_act = hb.p_act; tp.v_act = hb.v_act;
     static const int dbg = getenv("AZ_TOWER_DBG") ? atoi(getenv("AZ_TOWER_DBG")) : 0;
     tp.dbg = dbg;
-    tp.stamps = n->stamps;
+    tp.stamps = B <= n->max_batch ? n->stamps : nullptr;   // the stamp buffer holds max_batch positions' workgroups (the static-buffer entry point takes larger batches)
     const bool stamp = n->timing && (n->launches++ % TIMING_STRIDE == 0) && n->ev_used < TIMING_POOL;
     if (stamp) AZ_HIP(hipEventRecord(n->ev0[n->ev_used], s));
-    // form of the tower: whole positions per wave from 513 positions up, channel-split waves
+    // form of the tower: whole positions per wave from 513 positions up (k_tower16; 4 = k_tower, the
+    // same tiling on the 32x32x16 MFMA shape), channel-split waves
     // below (az_net_set_tower_form or AZ_TOWER_FORM force one; with stamps on the default is k_tower, whose stamps are always compiled in)
     static const int env_form = getenv("AZ_TOWER_FORM") ? atoi(getenv("AZ_TOWER_FORM")) : 0;
     const int forced = n->tower_form ? n->tower_form : env_form;
-    int form = forced ? forced : (B <= 256 ? 1 : (B <= 512 ? 2 : 4));
-    if ((n->stamps && !forced) || dbg) form = 4;
+    int form = forced ? forced : (B <= 256 ? 1 : (B <= 512 ? 2 : 16));
+    if (tp.stamps && !forced) form = 16;
+    if (dbg && !forced) form = 4;
     if (form == 1) hipLaunchKernelGGL((k_tower_split<1, 4>), dim3(B), dim3(256), 0, s, tp);
     else if (form == 2) hipLaunchKernelGGL((k_tower_split<2, 4>), dim3((B + 1) / 2), dim3(256), 0, s, tp);
     else if (form == 8) hipLaunchKernelGGL((k_tower_split<2, 8>), dim3((B + 3) / 4), dim3(512), 0, s, tp);

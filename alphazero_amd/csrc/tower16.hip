@@ -40,8 +40,13 @@ constexpr int L16_TOTAL = L16_SE + SE_BYTES;        // 159744
 // one 1 KB piece of an LDS-DMA copy whose global and LDS bases are both passed 4 KB in (the
 // immediate offset, -4096 ... 3072, is added to both).  M0 is written right before its use and not
 // restored: the compiler keeps nothing in it (a reserved register, set before each of its own uses).
+#ifndef AZ_T16_DIAG
+#define AZ_T16_DIAG 0
+#endif
 template <int OFF>
 __device__ __forceinline__ void glds16_piece(const void* gsrc_plus_4k, uint32_t lds_dst_plus_4k) {
+    if (AZ_T16_DIAG >= 2) return;
+    if (AZ_T16_DIAG == 1 && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) != 0) return;
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2"
                  :
                  : "v"(gsrc_plus_4k), "s"(lds_dst_plus_4k), "n"(OFF)
@@ -57,6 +62,7 @@ struct Frags16 {
 // then not loop invariants it could hoist (and spill)
 __device__ __forceinline__ void load_frags16(Frags16& f, const char* lds, const uint32_t (&a)[4], uint32_t wb,
                                              int ks, const uint32_t (&k16)[4]) {
+    if (AZ_T16_DIAG >= 4 && ks != 0) { asm volatile("" : "+v"(f.x[0]), "+v"(f.x[1]), "+v"(f.x[2]), "+v"(f.x[3])); return; }
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt) f.x[pt] = lds_read_frag(lds, ks ? (a[pt] ^ k16[ks]) : a[pt]);
 #pragma unroll
@@ -238,6 +244,7 @@ __global__ __launch_bounds__(256, 1) void k_tower16(TowerParams p) {
         // behind it, under that k-step's MFMAs.
         Frags16 f0, f1;
         load_frags16(f0, lds, aaddr[0], L16_W + ((conv * 9) & 1) * TAP_BYTES + lane * 16, 0, k16);
+        if (AZ_T16_DIAG >= 4) f1 = f0;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int T = conv * 9 + tap;
@@ -260,28 +267,28 @@ __global__ __launch_bounds__(256, 1) void k_tower16(TowerParams p) {
                     if (reads > 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 };
-                f1.x[0] = lds_read_frag(lds, aaddr[tap][0] ^ k16[1]);
-                f1.x[1] = lds_read_frag(lds, aaddr[tap][1] ^ k16[1]);
+                if (AZ_T16_DIAG < 4) f1.x[0] = lds_read_frag(lds, aaddr[tap][0] ^ k16[1]);
+                if (AZ_T16_DIAG < 4) f1.x[1] = lds_read_frag(lds, aaddr[tap][1] ^ k16[1]);
                 mma16<0, 1>(acc, f0); group(2);
                 glds16_piece<-4096>(src, dst);
-                f1.x[2] = lds_read_frag(lds, aaddr[tap][2] ^ k16[1]);
-                f1.x[3] = lds_read_frag(lds, aaddr[tap][3] ^ k16[1]);
+                if (AZ_T16_DIAG < 4) f1.x[2] = lds_read_frag(lds, aaddr[tap][2] ^ k16[1]);
+                if (AZ_T16_DIAG < 4) f1.x[3] = lds_read_frag(lds, aaddr[tap][3] ^ k16[1]);
                 mma16<1, 2>(acc, f0); group(2);
                 glds16_piece<-3072>(src, dst);
-                f1.w[0] = lds_read_frag(lds, wb + 8 * 1024);
-                f1.w[1] = lds_read_frag(lds, wb + 9 * 1024);
+                if (AZ_T16_DIAG < 4) f1.w[0] = lds_read_frag(lds, wb + 8 * 1024);
+                if (AZ_T16_DIAG < 4) f1.w[1] = lds_read_frag(lds, wb + 9 * 1024);
                 mma16<2, 3>(acc, f0); group(2);
                 glds16_piece<-2048>(src, dst);
-                f1.w[2] = lds_read_frag(lds, wb + 10 * 1024);
-                f1.w[3] = lds_read_frag(lds, wb + 11 * 1024);
+                if (AZ_T16_DIAG < 4) f1.w[2] = lds_read_frag(lds, wb + 10 * 1024);
+                if (AZ_T16_DIAG < 4) f1.w[3] = lds_read_frag(lds, wb + 11 * 1024);
                 mma16<3, 4>(acc, f0); group(2);
                 glds16_piece<-1024>(src, dst);
-                f1.w[4] = lds_read_frag(lds, wb + 12 * 1024);
-                f1.w[5] = lds_read_frag(lds, wb + 13 * 1024);
+                if (AZ_T16_DIAG < 4) f1.w[4] = lds_read_frag(lds, wb + 12 * 1024);
+                if (AZ_T16_DIAG < 4) f1.w[5] = lds_read_frag(lds, wb + 13 * 1024);
                 mma16<4, 5>(acc, f0); group(2);
                 glds16_piece<0>(src, dst);
-                f1.w[6] = lds_read_frag(lds, wb + 14 * 1024);
-                f1.w[7] = lds_read_frag(lds, wb + 15 * 1024);
+                if (AZ_T16_DIAG < 4) f1.w[6] = lds_read_frag(lds, wb + 14 * 1024);
+                if (AZ_T16_DIAG < 4) f1.w[7] = lds_read_frag(lds, wb + 15 * 1024);
                 mma16<5, 6>(acc, f0); group(2);
                 glds16_piece<1024>(src, dst);
                 mma16<6, 7>(acc, f0); group(0);
@@ -300,8 +307,10 @@ __global__ __launch_bounds__(256, 1) void k_tower16(TowerParams p) {
             mma16<0, 8>(acc, f0);
             interleave16();
             // k-step 3, behind the barrier
+            if (AZ_T16_DIAG < 3) {
             wait_weights();
             __syncthreads();  // next tap landed; everyone is done reading this buffer
+            }
             if (tap + 1 < 9) load_frags16(f0, lds, aaddr[tap + 1 < 9 ? tap + 1 : 0], wb_next, 0, k16);
             mma16<0, 8>(acc, f1);
             interleave16();
