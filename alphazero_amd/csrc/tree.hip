@@ -268,6 +268,14 @@ __global__ __launch_bounds__(64) void k_set_root(EngineView E, int g, int64_t no
     reroot_subtree(E, g, (uint32_t)node, lane);
 }
 
+// az_engine_import_tree: the arrays are in the live arena already; publish the tree
+__global__ void k_import_tree(EngineView E, int g, uint32_t n_nodes, int root64) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        E.root[g] = 0; E.used[g] = n_nodes; E.root_mode[g] = (uint8_t)(root64 ? 1 : 0); E.leaf_need[g] = 0;
+    }
+}
+__global__ void k_read_arena(EngineView E, int g, uint8_t* out) { *out = E.arena[g]; }
+
 // batched form: block i re-roots game slots[i] at nodes[i] (negative: drop the tree)
 __global__ __launch_bounds__(64) void k_set_roots(EngineView E, int n, const int32_t* slots, const int64_t* nodes) {
     const int lane = threadIdx.x;
@@ -684,6 +692,57 @@ extern "C" int az_engine_set_roots(az_engine* e, int32_t n, const int32_t* slots
     hipLaunchKernelGGL(k_set_roots, dim3(n), dim3(64), 0, s, e->v, n, e->stage_slots, nodes_dev);
     AZ_HIP(hipGetLastError());
     AZ_HIP(hipStreamSynchronize(s));  // the staging buffers and host arrays are free again
+    return AZ_OK;
+}
+
+extern "C" int az_engine_import_tree(az_engine* e, int32_t g, int32_t n_nodes, const uint32_t* visits_host,
+                                     const float* value_sum_host, const float* prior_host,
+                                     const uint32_t* first_child_host, const uint8_t* n_children_host,
+                                     const uint8_t* action_host, const uint8_t* uniform64_host,
+                                     const double* root_prior64_host, void* stream) {
+    AZ_CHECK_ARG(e, "az_engine_import_tree: null engine");
+    AZ_CHECK_ARG(g >= 0 && g < e->v.B, "az_engine_import_tree: game %d out of range", g);
+    AZ_CHECK_ARG(n_nodes >= 1 && (uint32_t)n_nodes <= e->v.cap, "az_engine_import_tree: %d nodes, the pool holds %u per game",
+                 n_nodes, e->v.cap);
+    AZ_CHECK_ARG(visits_host && value_sum_host && prior_host && first_child_host && n_children_host && action_host,
+                 "az_engine_import_tree: null array");
+    // every node's children must be one block behind the node itself, inside the tree; every
+    // block disjoint from the others (breadth-first order gives that: blocks in ascending order)
+    std::vector<uint32_t> info(n_nodes);
+    uint32_t next_block = 1;
+    for (int i = 0; i < n_nodes; ++i) {
+        const uint32_t k = n_children_host[i], fc = first_child_host[i];
+        AZ_CHECK_ARG(k <= (uint32_t)MAX_CHILDREN, "az_engine_import_tree: node %d has %u children (at most %d)", i, k, MAX_CHILDREN);
+        AZ_CHECK_ARG(action_host[i] < NUM_ACTIONS || i == 0, "az_engine_import_tree: node %d has action %u", i, action_host[i]);
+        if (k) {
+            AZ_CHECK_ARG(fc == next_block && (uint64_t)fc + k <= (uint64_t)n_nodes,
+                         "az_engine_import_tree: the children of node %d are not the next block of the breadth-first order", i);
+            next_block = fc + k;
+        }
+        const uint32_t flags = (uniform64_host && uniform64_host[i] && k) ? FLAG_UNIFORM64 : 0u;
+        info[i] = (uint32_t)(action_host[i] % NUM_ACTIONS) | (k << 8) | (flags << 16);
+    }
+    AZ_CHECK_ARG(next_block == (uint32_t)n_nodes, "az_engine_import_tree: %d nodes given, %u reachable", n_nodes, next_block);
+    hipStream_t s = (hipStream_t)stream;
+    uint8_t* arena_dev = reinterpret_cast<uint8_t*>(e->stage_win);
+    uint8_t arena = 0;
+    hipLaunchKernelGGL(k_read_arena, dim3(1), dim3(1), 0, s, e->v, g, arena_dev);
+    AZ_HIP(hipGetLastError());
+    AZ_HIP(hipMemcpyAsync(&arena, arena_dev, 1, hipMemcpyDeviceToHost, s));
+    AZ_HIP(hipStreamSynchronize(s));
+    const size_t base = ((size_t)g * 2 + (arena & 1)) * e->v.cap;
+    const size_t n = (size_t)n_nodes;
+    AZ_HIP(hipMemcpyAsync(e->v.N + base, visits_host, n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    AZ_HIP(hipMemcpyAsync(e->v.W + base, value_sum_host, n * sizeof(float), hipMemcpyHostToDevice, s));
+    AZ_HIP(hipMemcpyAsync(e->v.P + base, prior_host, n * sizeof(float), hipMemcpyHostToDevice, s));
+    AZ_HIP(hipMemcpyAsync(e->v.FC + base, first_child_host, n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    AZ_HIP(hipMemcpyAsync(e->v.IN + base, info.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    if (root_prior64_host)
+        AZ_HIP(hipMemcpyAsync(e->v.root_p64 + (size_t)g * MAX_CHILDREN, root_prior64_host,
+                              (size_t)n_children_host[0] * sizeof(double), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_import_tree, dim3(1), dim3(64), 0, s, e->v, g, (uint32_t)n_nodes, root_prior64_host ? 1 : 0);
+    AZ_HIP(hipGetLastError());
+    AZ_HIP(hipStreamSynchronize(s));  // the host arrays are free again
     return AZ_OK;
 }
 

@@ -224,6 +224,18 @@ class Engine:
         assert len(slots) == len(nodes)
         self._call("az_engine_set_roots", self.h, len(slots), _host_ptr(slots), _host_ptr(nodes), _stream(self.device))
 
+    def import_tree(self, g, visits, value_sum, prior, first_child, n_children, action, uniform64=None, root_prior64=None):
+        """Game g's tree becomes the host-built one given as breadth-first arrays (az_engine_import_tree)."""
+        n = len(visits)
+        arr = [np.ascontiguousarray(visits, np.uint32), np.ascontiguousarray(value_sum, np.float32),
+               np.ascontiguousarray(prior, np.float32), np.ascontiguousarray(first_child, np.uint32),
+               np.ascontiguousarray(n_children, np.uint8), np.ascontiguousarray(action, np.uint8)]
+        assert all(len(a) == n for a in arr)
+        u = None if uniform64 is None else np.ascontiguousarray(uniform64, np.uint8)
+        r = None if root_prior64 is None else np.ascontiguousarray(root_prior64, np.float64)
+        self._call("az_engine_import_tree", self.h, int(g), n, *[_host_ptr(a) for a in arr], _host_ptr(u), _host_ptr(r),
+                   _stream(self.device))
+
     def pool_usage(self):
         used = np.zeros(self.n, np.uint32)
         self._call("az_engine_pool_usage", self.h, _host_ptr(used), _stream(self.device))

@@ -138,6 +138,50 @@ class Node:
         return len(self.children) > 0
 
 
+def _flatten_host_tree(root):
+    """Breadth-first arrays of a host-built Node tree for Engine.import_tree, and the Node
+    objects in that order.  Types: visit counts int; value sums float32 (what a search leaves
+    in them); priors float32, except (i) at the root, where any prior that is not a numpy
+    float32 puts all of the root's priors in float64, the state _add_dirichlet_noise leaves
+    (src/mcts.py:314-326), and (ii) below the root, where k children that all hold the Python
+    float 1/k are the uniform fallback of _expand_node (src/mcts.py:277-278).  Any other plain
+    Python float below the root is rounded to float32."""
+    nodes, first, count, action = [root], [0], [0], [0]
+    i = 0
+    while i < len(nodes):
+        ch = nodes[i]._children or {}
+        if len(ch) > 48:
+            raise _lib.AzError(f"a Node with {len(ch)} children: a Breakthrough position has at most 48 moves")
+        if ch:
+            first[i], count[i] = len(nodes), len(ch)
+            for a, c in ch.items():
+                if not (0 <= int(a) < NUM_ACTIONS):
+                    raise _lib.AzError(f"child key {a!r} is not an action index")
+                nodes.append(c)
+                first.append(0)
+                count.append(0)
+                action.append(int(a))
+        i += 1
+        if len(nodes) > (1 << 17):
+            raise _lib.AzError("the host tree has more nodes than an engine slot holds (or refers to itself)")
+    uniform = np.zeros(len(nodes), np.uint8)
+    for i, nd in enumerate(nodes):
+        k = count[i]
+        if i > 0 and k and all(type(nodes[first[i] + j]._prior) is float and nodes[first[i] + j]._prior == 1.0 / k
+                               for j in range(k)):
+            uniform[i] = 1
+    root_p64 = None
+    k0 = count[0]
+    if k0 and not all(isinstance(nodes[1 + j]._prior, np.float32) for j in range(k0)):
+        root_p64 = np.array([float(nodes[1 + j]._prior) for j in range(k0)], np.float64)
+    arrays = dict(visits=np.array([int(nd._visit_count) for nd in nodes], np.uint32),
+                  value_sum=np.array([np.float32(nd._value_sum) for nd in nodes], np.float32),
+                  prior=np.array([np.float32(nd._prior) for nd in nodes], np.float32),
+                  first_child=np.array(first, np.uint32), n_children=np.array(count, np.uint8),
+                  action=np.array(action, np.uint8), uniform64=uniform, root_prior64=root_p64)
+    return arrays, nodes
+
+
 class _SlotPool:
     """Engines are created on demand; each serves up to `capacity` trees."""
 
@@ -213,15 +257,14 @@ class MCTS:
                 raise _lib.AzError("this root belongs to a tree built by another MCTS object: search it with that "
                                    "object, or pass root=None to start a fresh tree")
         fresh = [i for i in range(n) if not (isinstance(roots[i], Node) and roots[i]._tree is not None)]
-        for i in fresh:
-            r = roots[i]
-            if r is not None and r._tree is None and len(r._children or {}) > 0:
-                raise NotImplementedError("searching from a hand-built host tree is not supported")
         got = self._pool.acquire(len(fresh))
         for i, (eng, slot) in zip(fresh, got):
             tree = _Tree(self._pool, eng, slot)
             if roots[i] is None:
                 roots[i] = Node(0)
+            # a root the caller built by hand (src/mcts.py:117-125 takes any Node): its tree goes
+            # up once the position is set
+            tree.upload = _flatten_host_tree(roots[i]) if roots[i]._children else None
             roots[i]._bind(tree, -1)
         by_engine: Dict[int, List[int]] = {}
         for i in range(n):
@@ -315,6 +358,15 @@ class MCTS:
         new = np.array([r._idx < 0 for r in roots])
         if new.any():
             engine.set_positions(slots[new], white[new], black[new], turn[new], winner[new])
+            for r in roots:
+                t = r._tree
+                if r._idx < 0 and getattr(t, "upload", None) is not None:
+                    arrays, nodes = t.upload
+                    engine.import_tree(t.slot, **arrays)
+                    t.upload = None
+                    t.root_idx = 0
+                    for idx, node in enumerate(nodes):     # the caller's Node objects become handles
+                        node._bind(t, idx)
         if (~new).any():
             engine.update_positions(slots[~new], white[~new], black[~new], turn[~new], winner[~new])
         move_slots, move_nodes = [], []       # re-root reused trees at the node that was passed in

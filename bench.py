@@ -16,9 +16,14 @@ SE-ResNet tower) against the dense bf16 MFMA peak using HIP-event timings taken
 inside the timed region.  `cpu_baseline` times the CPU oracle (C tree + float32
 torch forward) as P independent single-thread processes x 128 games playing
 the same self-play loop on the host cores, before the GPU is touched.
+For N > 1 the CPU leg runs once per job: in the parent when the script starts its
+own ranks, on rank 0 before it joins the process group when a launcher started them.
 `secondary` (N = 1) times the move-generation kernel (BASELINE config 2) and
 the batch-4096 network forward (config 3) with HIP events after the timed
-region; it does not enter `value`.
+region, then plays one whole episode batch (every game to its end, the batch
+shrinking as in the reference's execute_parallel_episodes: seconds, sims/s,
+positions/s, games/s) and a stretch of continuous play with the games spread over
+all stages of a game; none of it enters `value`.
 """
 import argparse
 import json
@@ -234,6 +239,73 @@ def secondary_block(blocks):
     return out
 
 
+def whole_game_block(args):
+    """What the timed region (opening plies only) does not show: games played to the end.
+    episode: the reference's execute_parallel_episodes (src/parallel_trainer.py:158-217) at the
+    benchmark size, every game to its end, finished games leave the batch.  sustained: continuous
+    play (a finished game restarts at once) once the games are spread over all stages of a game:
+    before the clock starts game g plays g-dependent 0..55 opening plies at 16 simulations a move."""
+    from alphazero_amd.model import AlphaZeroNet
+    from alphazero_amd.selfplay import SelfPlay
+    torch.manual_seed(0)
+    sp = SelfPlay(AlphaZeroNet(num_blocks=args.blocks, num_filters=128).eval(), n_games=args.games,
+                  num_simulations=args.sims, seed=4321)
+    e = sp.engine
+    out = {}
+    # ---- one episode batch
+    e.reset_all()
+    e.set_active(np.ones(args.games, np.uint8))
+    torch.cuda.synchronize()
+    st0 = e.stats()
+    t0 = time.perf_counter()
+    plies = 0
+    while e.stats()["games_finished"] - st0["games_finished"] < args.games:
+        e.play_move(args.sims, add_noise=True, restart_finished=False)
+        plies += 1
+        if e.samples_pending() > args.games * 64:
+            e.drain_samples()
+    e.drain_samples()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st1 = e.stats()
+    d = {k: st1[k] - st0[k] for k in ("simulations", "moves", "games_finished", "nn_evals")}
+    out["episode"] = {"what": f"{args.games} games x {args.sims} sims/move played to the end, finished games leave the batch "
+                              "(the reference's execute_parallel_episodes); samples drained on the device inside the timed region",
+                      "seconds": dt, "plies_of_the_longest_game": plies, "games": d["games_finished"], "positions": d["moves"],
+                      "simulations": d["simulations"], "sims_per_sec": d["simulations"] / dt,
+                      "positions_per_sec": d["moves"] / dt, "games_per_sec": d["games_finished"] / dt}
+    # ---- continuous play in the steady state
+    e.reset_all()
+    rs = np.random.RandomState(7)
+    offset = rs.randint(0, 56, size=args.games)
+    for j in range(int(offset.max())):
+        e.set_active((offset > j).astype(np.uint8))
+        e.play_move(16, add_noise=True, restart_finished=True)
+    e.set_active(np.ones(args.games, np.uint8))
+    e.drain_samples()
+    torch.cuda.synchronize()
+    st0 = e.stats()
+    t0 = time.perf_counter()
+    for i in range(args.sustained_plies):
+        e.play_move(args.sims, add_noise=True, restart_finished=True)
+        if (i + 1) % 16 == 0 and e.samples_pending() > 32768:
+            e.drain_samples()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st1 = e.stats()
+    d = {k: st1[k] - st0[k] for k in ("simulations", "moves", "games_finished", "nn_evals")}
+    out["sustained"] = {"what": f"{args.sustained_plies} plies of continuous play, {args.games} games x {args.sims} sims/move, finished "
+                                "games restart at once; before the clock starts the games are spread over the stages of a game "
+                                "(game g plays 0..55 opening plies at 16 sims/move)",
+                        "seconds": dt, "plies": args.sustained_plies, "games_finished": d["games_finished"],
+                        "positions": d["moves"], "simulations": d["simulations"], "sims_per_sec": d["simulations"] / dt,
+                        "positions_per_sec": d["moves"] / dt, "games_per_sec": d["games_finished"] / dt,
+                        "terminal_leaf_share": 1.0 - d["nn_evals"] / max(1, d["simulations"] + d["moves"])}
+    del sp, e
+    torch.cuda.empty_cache()
+    return out
+
+
 # ----------------------------------------------------------------------------
 
 def free_port():
@@ -247,10 +319,15 @@ def free_port():
 def self_launch(args):
     """N > 1 without a launcher: start the N ranks as child processes of this one, which has
     made no GPU call, relay rank 0's JSON line and exit with the launcher's status."""
+    # the CPU leg runs here, on a host that is otherwise idle, before any rank exists
+    cpu = None
+    if args.cpu_seconds > 0 and not args.exchange_only:
+        cpu = cpu_baseline(args.sims, args.blocks, args.cpu_seconds)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["AZ_BENCH_CPU_LEG_DONE"] = "1"      # the ranks skip it
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, cwd=os.getcwd())
     line = None
     for raw in proc.stdout:
@@ -261,6 +338,10 @@ def self_launch(args):
             sys.stderr.write(text)
     rc = proc.wait()
     if line is not None:
+        if cpu is not None:
+            merged = json.loads(line)
+            merged["cpu_baseline"] = cpu
+            line = json.dumps(merged)
         print(line, flush=True)
     elif rc == 0:
         rc = 1
@@ -277,7 +358,9 @@ def main():
     ap.add_argument("--sims", type=int, default=800, help="simulations per move")
     ap.add_argument("--blocks", type=int, default=20)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="0 disables the CPU baseline leg")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the config 2 / config 3 measurements")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the config 2 / config 3 measurements and the whole-game block")
+    ap.add_argument("--no-whole-games", action="store_true", help="skip secondary.episode / secondary.sustained (about a minute)")
+    ap.add_argument("--sustained-plies", type=int, default=48)
     ap.add_argument("--exchange-only", action="store_true",
                     help="N > 1: time only the two exchange steps (sample all-gather, data-parallel training "
                          "step); no self-play, value = 0.  With AZ_BENCH_BACKEND=gloo this needs no GPU")
@@ -297,8 +380,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     # CPU leg first: its worker processes are started while this process has made no GPU call
+    # (N > 1 under a launcher: rank 0 runs it while the other ranks wait in the rendezvous, idle)
     cpu = None
-    if world == 1 and args.cpu_seconds > 0:
+    if rank == 0 and args.cpu_seconds > 0 and not args.exchange_only and not os.environ.get("AZ_BENCH_CPU_LEG_DONE"):
         cpu = cpu_baseline(args.sims, args.blocks, args.cpu_seconds)
 
     backend = os.environ.get("AZ_BENCH_BACKEND", "nccl")
@@ -388,7 +472,7 @@ def main():
         # HBM-side bytes per tower launch come from separate rocprofv3 --pmc passes
         # (profiles/): counters cannot be read from inside this process
         traffic, traffic_source = None, None
-        for name in ("r02_k_tower_pmc.json", "r01_k_tower_pmc.json"):
+        for name in ("r03_k_tower16_pmc.json",):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc) and args.games == 1024 and args.blocks == 20:
                 traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
@@ -409,7 +493,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "bf16",
-            "data": "synthetic (random-init weights, games from the start position)",
+            "data": "synthetic (random-init weights, games from the start position; the timed region covers opening plies, "
+                    "secondary.sustained / secondary.episode cover whole games)",
             "config": {"workload": f"full self-play: {args.games} concurrent games/GPU x {args.sims} sims/move, "
                                    f"Dirichlet noise, SE-ResNet {args.blocks}x128, tree reuse, restart on finish",
                        "games_per_gpu": args.games, "sims_per_move": args.sims,
@@ -417,7 +502,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_BF16_DENSE / 1e12,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_DENSE, "traffic": traffic,
                          "traffic_source": traffic_source,
-                         "kernel": "k_tower" if args.games > 512 else ("k_tower_split<2>" if args.games > 256 else "k_tower_split<1>"),
+                         "kernel": "k_tower16" if args.games > 512 else ("k_tower_split<2>" if args.games > 256 else "k_tower_split<1>"),
                          "launch_ms": tower_ms, "launch_samples": tower_samples,
                          "flop_per_launch": flop_launch,
                          "rows_per_launch": rows_per_launch,
@@ -436,6 +521,15 @@ def main():
                 out["secondary"] = secondary_block(args.blocks)
             except Exception as exc:           # the headline line must still be printed
                 out["secondary"] = {"error": repr(exc)}
+            if not args.no_whole_games:
+                try:
+                    out["secondary"].update(whole_game_block(args))
+                    out["games_per_sec"] = out["secondary"]["sustained"]["games_per_sec"]
+                    out["games_per_sec_is"] = "secondary.sustained (continuous play in the steady state; the timed region " \
+                                              "plays opening plies, where no game ends); secondary.episode has the " \
+                                              "reference's shrinking-batch figure"
+                except Exception as exc:
+                    out["secondary"]["whole_games_error"] = repr(exc)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

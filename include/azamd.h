@@ -225,6 +225,22 @@ int az_engine_set_root(az_engine* e, int32_t g, int64_t node, void* stream);
  * the game's tree is reported by the next call that checks the engine's error flag. */
 int az_engine_set_roots(az_engine* e, int32_t n, const int32_t* slots_host, const int64_t* nodes_host, void* stream);
 
+/* A tree the caller built on the host becomes game g's tree (search_batch accepts any Node as a
+ * root, src/mcts.py:117-125; Node, src/mcts.py:21-40).  Nodes in breadth-first order, node 0 the
+ * root, the children of a node one contiguous block in insertion order: first_child_host[i],
+ * n_children_host[i] (0: a leaf).  visits / value_sum / prior / action as the reference's
+ * visit_count, value_sum (held as float32, what a search leaves there), prior (float32) and the
+ * key in the parent's children (ignored for the root).  uniform64_host[i] != 0 (array may be
+ * NULL): node i's children hold the float64 prior 1/k of src/mcts.py:277-278.
+ * root_prior64_host (NULL, or one double per child of the root): the root's children hold
+ * float64 priors, as after _add_dirichlet_noise (src/mcts.py:314-326).  The game's position is
+ * whatever az_engine_set_positions gave it.  Synchronises the stream. */
+int az_engine_import_tree(az_engine* e, int32_t g, int32_t n_nodes, const uint32_t* visits_host,
+                          const float* value_sum_host, const float* prior_host,
+                          const uint32_t* first_child_host, const uint8_t* n_children_host,
+                          const uint8_t* action_host, const uint8_t* uniform64_host,
+                          const double* root_prior64_host, void* stream);
+
 /* Diagnostics: nodes in use per game.  Like every call that synchronises, it reports a
  * pending device-side error (node pool exhausted, path too deep, bad node index, sample
  * queue full).  A condition is reported once and then cleared: the engine stays usable,

@@ -137,6 +137,78 @@ def test_full_size_plies_keep_the_search_invariants():
     assert len(s) == 0                                                    # no game has finished
 
 
+def test_full_size_fused_search_equals_the_oracle_on_sampled_games():
+    """The benchmark's own size and kernel form: 1024 games x 800 simulations through the fused
+    search with the 20 x 128 network (the large-batch tower at 1024 rows, device row assignment)
+    and injected root noise, two plies with tree reuse.  Eight games spread over the batch are
+    replayed by the CPU oracle, which is given the same network's outputs through the same
+    tower form at 8 rows (a position's outputs do not depend on its row or its neighbours):
+    identical visit counts, value sums and priors.  Reference: MCTS.search_batch
+    (src/mcts.py:94-189)."""
+    from alphazero_amd.engine import Engine
+    from alphazero_amd.model import AlphaZeroNet, HipInference
+    nG, S = 1024, 800
+    torch.manual_seed(0)
+    model = AlphaZeroNet(num_blocks=20, num_filters=128).eval()
+    inf = HipInference(model, max_batch=nG)
+    w, b, t, win = orc.random_positions(4000, seed=33)
+    idx = [i for i in range(4000) if win[i] == 0 and orc.legal_actions(orc.make_pos(w[i], b[i], t[i])).size][:nG]
+    assert len(idx) == nG
+    idx = np.asarray(idx)
+    dev = Engine(nG)
+    dev.set_positions(np.arange(nG), w[idx], b[idx], t[idx])
+    dev.attach_net(inf)
+    sel = np.array([0, 1, 127, 300, 511, 512, 777, 1023])
+    cpu = orc.OracleMCTS(len(sel))
+    for j, g in enumerate(sel):
+        cpu.set_game(j, orc.make_pos(w[idx[g]], b[idx[g]], t[idx[g]]))
+    small = HipInference(model, max_batch=16)
+    small.set_tower_form(16)                      # the form the 1024-row launches use
+    start = orc.encode_state(orc.start_position())
+
+    def evaluate(planes, need):
+        x = np.ascontiguousarray(planes, np.float32).copy()
+        x[np.asarray(need) == 0] = start
+        probs, value, _, _ = small.forward_planes(torch.from_numpy(x).cuda())
+        return probs.cpu().numpy().copy(), value.cpu().numpy().copy()
+
+    rs = np.random.RandomState(11)
+    pos = [orc.make_pos(w[i], b[i], t[i]) for i in idx]
+    alive = np.ones(nG, bool)
+    compared = 0
+    for ply in range(2):
+        dev.set_active(alive.astype(np.uint8)); cpu.set_active(alive[sel])
+        noise = rs.dirichlet([0.35] * 48, size=nG)
+        dev.search(0, add_noise=False)                # expands the roots that need it
+        dev.add_noise(noise)
+        dev.search(S, add_noise=False)
+        cpu.search(evaluate, S, noise=noise[sel])
+        for j, g in enumerate(sel):
+            if not alive[g]:
+                continue
+            a, o = dev.root_children(int(g)), cpu.root_children(j)
+            assert np.array_equal(a["actions"], o["actions"])
+            assert np.array_equal(a["N"], o["N"]), (ply, int(g))
+            assert np.array_equal(a["W"].view(np.uint32), o["W"].view(np.uint32)), (ply, int(g))
+            assert np.array_equal(a["P"].view(np.uint64), o["P"].view(np.uint64)), (ply, int(g))
+            compared += 1
+        # every live game plays its most-visited move (first in insertion order among ties)
+        acts = np.full(nG, -1, np.int16)
+        live = np.flatnonzero(alive)
+        for g, q in zip(live, dev.roots_children(live)):
+            acts[g] = int(q["actions"][np.argmax(q["N"])])
+            pos[g] = orc.step_action(pos[g], int(acts[g]))
+        for j, g in enumerate(sel):
+            if alive[g]:
+                cpu.advance(j, int(acts[g]))
+        dev.advance_all(acts)
+        for g in live:
+            if orc.is_terminal(pos[g]):
+                alive[g] = False
+    assert compared >= 12
+    small.close()
+
+
 def test_fused_search_with_the_real_network_equals_the_oracle(small_model):
     """The whole fused path (HIP network inside the library, 800 simulations, injected root
     noise, tree reuse over two plies) against the CPU oracle driven with the same network's
@@ -309,7 +381,9 @@ def test_fused_sample_stream_equals_the_reference_stream(golden_dir, small_model
 def test_bench_starts_its_own_ranks_on_the_gpu():
     """`python bench.py --gpus 2` with WORLD_SIZE unset: the script starts two ranks itself, both
     play on this box's one GPU (gloo rehearsal of the collectives) and rank 0's single JSON
-    line is relayed with the whole-job counts."""
+    line is relayed with the whole-job counts.  The CPU baseline leg runs once per job and is
+    part of that line: in the parent when bench.py starts the ranks, on rank 0 (before it joins
+    the process group) when a launcher started them, as the round-end driver does."""
     import json
     import os
     import subprocess
@@ -317,17 +391,22 @@ def test_bench_starts_its_own_ranks_on_the_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["AZ_BENCH_BACKEND"] = "gloo"
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--games", "32", "--sims", "16", "--blocks", "2", "--cpu-seconds", "0"],
-                       env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1, r.stdout
-    out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak"
-    # two ranks x 32 games x 16 simulations x 2 plies
-    assert round(out["value"] * out["ms_per_step"] * 1e-3 * 2) == 2 * 32 * 16 * 2
-    assert "error" not in out["exchange"] and out["exchange"]["backend"] == "gloo"
+    args = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--games", "32", "--sims", "16", "--blocks", "2",
+            "--cpu-seconds", "1.5"]
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                "127.0.0.1", "--master-port", "29731"]
+    for cmd in ([sys.executable, os.path.join(root, "bench.py")] + args, launcher + [os.path.join(root, "bench.py")] + args):
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.strip().startswith('{"metric"')]
+        assert len(lines) == 1, r.stdout
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak"
+        # two ranks x 32 games x 16 simulations x 2 plies
+        assert round(out["value"] * out["ms_per_step"] * 1e-3 * 2) == 2 * 32 * 16 * 2
+        assert "error" not in out["exchange"] and out["exchange"]["backend"] == "gloo"
+        cpu = out["cpu_baseline"]
+        assert cpu["kind"] == "port" and cpu["unit"] == "sims/s" and cpu["value"] > 0 and cpu["cores"] >= 1
 
 
 def test_packed_samples_unpack_to_the_drained_arrays(small_model):
