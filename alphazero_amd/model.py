@@ -131,7 +131,7 @@ class HipInference:
             _lib.check(_lib.lib().az_net_load_state(self.h, C.c_void_p(blob.data_ptr()), blob.numel()))
 
     def set_tower_form(self, form=0):
-        """0: by batch size; 1, 2, 4, 8: force that form of the tower kernel."""
+        """0: by batch size; 1, 2, 4, 8, 16: force that form of the tower kernel."""
         _lib.check(_lib.lib().az_net_set_tower_form(self.h, int(form)))
 
     def set_timing(self, enable=True):
@@ -183,9 +183,21 @@ class HipInference:
         """az_net_forward_noalloc: like forward_bits for at most 256 positions, writing into
         tensors the caller already owns; neither this wrapper nor the library allocates."""
         B = mine.numel()
-        _lib.check(_lib.lib().az_net_forward_noalloc(
-            self.h, B, self._p(mine), self._p(theirs), self._p(probs), self._p(value), self._p(policy_logits),
-            self._p(wl_logits), C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        assert mine.dtype == torch.int64 and theirs.dtype == torch.int64 and theirs.numel() == B
+        assert mine.is_contiguous() and theirs.is_contiguous()
+        for name, t, row in (("probs", probs, 192), ("value", value, 1), ("policy_logits", policy_logits, 192),
+                             ("wl_logits", wl_logits, 2)):
+            if t is None:
+                assert name not in ("probs", "value"), f"{name} is required"
+                continue
+            assert t.dtype == torch.float32 and t.is_contiguous(), f"{name} must be a contiguous float32 tensor"
+            assert t.numel() >= B * row, f"{name} holds {t.numel()} elements, {B} positions need {B * row}"
+        for t in (mine, theirs, probs, value, policy_logits, wl_logits):
+            assert t is None or t.device == self.device, "a tensor lives on another device"
+        with torch.cuda.device(self.device):     # the library checks that the network's device is current
+            _lib.check(_lib.lib().az_net_forward_noalloc(
+                self.h, B, self._p(mine), self._p(theirs), self._p(probs), self._p(value), self._p(policy_logits),
+                self._p(wl_logits), C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
 
     def forward_planes(self, planes, want_logits=False):
         """planes: [B,3,8,8] float32 cuda tensor of encoded states."""

@@ -94,7 +94,11 @@ class ExampleArrays:
         self._np = (st, po, wl)
         self._t = None
 
+    def _load(self):
+        """Hook of views that fetch their contents on first use (ReplayView)."""
+
     def _host(self):
+        self._load()
         if self._np is None:
             self._np = tuple(x.cpu().numpy() for x in self._t)
         return self._np
@@ -114,6 +118,7 @@ class ExampleArrays:
     def tensors(self, device):
         """(states, policies, wls) as float32 torch tensors on `device`."""
         device = _concrete(device)
+        self._load()
         if self._t is not None and self._t[0].device == device:
             return self._t
         if self._t is not None and self._np is None:
@@ -131,9 +136,11 @@ class ExampleArrays:
                    np.stack([e[2] for e in examples]))
 
     def __len__(self):
+        self._load()
         return len(self._np[0]) if self._np is not None else int(self._t[0].shape[0])
 
     def __getitem__(self, i):
+        self._load()
         if isinstance(i, slice):
             if self._np is None:
                 return ExampleArrays(self._t[0][i], self._t[1][i], self._t[2][i])
@@ -158,6 +165,8 @@ class ExampleArrays:
             return ExampleArrays()
         if len(parts) == 1:
             return parts[0]
+        for p in parts:
+            p._load()
         devs = {p._t[0].device for p in parts if p._t is not None and p._np is None}
         if len(devs) == 1 and all(p._t is not None for p in parts):
             dev = devs.pop()
@@ -165,6 +174,37 @@ class ExampleArrays:
             return ExampleArrays(*(torch.cat([t[i] for t in ts]) for i in range(3)))
         return ExampleArrays(np.concatenate([p.states for p in parts]), np.concatenate([p.policies for p in parts]),
                              np.concatenate([p.wls for p in parts]))
+
+
+class ReplayView(ExampleArrays):
+    """What `trainer.examples` returns: the replay buffer read like the reference's list
+    (src/parallel_trainer.py:127, 437-442).  `len()` is answered from the ring; the rows are
+    copied out of it (oldest first, on the training device) only when they are first touched.
+    `extend` and `+=` append to the ring itself, as they would to the reference's list."""
+
+    __slots__ = ("_trainer",)
+
+    def __init__(self, trainer):
+        self._np = self._t = None
+        self._trainer = trainer
+
+    def _load(self):
+        if self._np is None and self._t is None:
+            snap = self._trainer._replay.ordered()
+            self._np, self._t = snap._np, snap._t
+
+    def __len__(self):
+        if self._np is None and self._t is None:
+            return len(self._trainer._replay)
+        return ExampleArrays.__len__(self)
+
+    def extend(self, other):
+        self._trainer.add_examples(other)
+        self._np = self._t = None            # read again from the ring when next touched
+
+    def __iadd__(self, other):
+        self.extend(other)
+        return self
 
 
 class ReplayRing:
@@ -310,16 +350,19 @@ class ParallelTrainer:
     # ------------------------------------------------------------------ replay buffer
     @property
     def examples(self) -> ExampleArrays:
-        """The replay buffer, oldest example first.  The rows live on the training device;
-        the numpy arrays behind this view are made when they are first read."""
+        """The replay buffer, oldest example first.  The rows live on the training device; `len()`
+        costs nothing, the rows are copied out of the ring when first touched and the numpy arrays
+        behind the view are made when they are first read."""
         view, version = self._examples_view
         if version != self._replay.version:
-            view = self._replay.ordered()
+            view = ReplayView(self)
             self._examples_view = (view, self._replay.version)
         return view
 
     @examples.setter
     def examples(self, value):
+        if isinstance(value, ReplayView) and value._trainer is self:
+            return                           # `trainer.examples += x` hands the view back: already appended
         self._replay.clear()
         self._replay.append(ExampleArrays.of(value), self.max_examples)
 

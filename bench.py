@@ -541,8 +541,32 @@ def exchange_block(args, dist, model, rank, world, coll_dev, backend, barrier):
     every rank's replay buffer, then one data-parallel training step at global batch 1024
     with a gradient all-reduce (RCCL when backend is nccl)."""
     from alphazero_amd.model import AlphaZeroNet
-    try:
-        from alphazero_amd.distributed import all_gather_packed, train_step
+
+    def all_ok(ok):
+        """True when every rank got here without an error: a rank that failed on its own must not
+        leave the others waiting inside the next collective."""
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=coll_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
+
+    state, err = {}, None
+
+    def stage(fn):
+        """Runs fn (local work only) on this rank unless an earlier stage failed somewhere; then all
+        ranks agree on whether to go on.  The collectives themselves sit between stages."""
+        nonlocal err
+        if err is None:
+            try:
+                fn()
+            except Exception as exc:
+                err = repr(exc)
+        if not all_ok(err is None):
+            err = err or "another rank failed in this stage"
+            return False
+        return True
+
+    def prepare():
+        from alphazero_amd.distributed import all_gather_packed, train_step  # noqa: F401
         from alphazero_amd._lib import PACKED_SAMPLE_BYTES
         n_s = args.games * 64
         g = torch.Generator(device=coll_dev).manual_seed(rank)
@@ -552,44 +576,54 @@ def exchange_block(args, dist, model, rank, world, coll_dev, backend, barrier):
         fl[:, 0] = 1.0
         fl[:, 2:] = torch.softmax(torch.rand((n_s, 192), device=coll_dev, generator=g), 1)
         packed[:, :16] = torch.randint(0, 2, (n_s, 16), device=coll_dev, generator=g, dtype=torch.uint8)
-        all_gather_packed(packed[:16])                # warm-up (RCCL channels)
-        barrier()
-        t1 = time.perf_counter()
-        gathered = all_gather_packed(packed)
-        barrier()
-        t_gather = time.perf_counter() - t1
+        state.update(packed=packed, n_s=n_s, row=PACKED_SAMPLE_BYTES)
+
+    def unpack():
+        gathered = state.pop("gathered")
         if gathered.is_cuda:
             from alphazero_amd.engine import unpack_samples
             t1 = time.perf_counter()
             G = unpack_samples(gathered)
             torch.cuda.synchronize()
-            t_unpack = time.perf_counter() - t1
+            state["t_unpack"] = time.perf_counter() - t1
         else:                                         # gloo rehearsal: the unpack kernel needs the rows on a GPU
             fl = gathered[:, 16:].view(torch.float32)
             G = (torch.zeros((len(gathered), 3, 8, 8)), fl[:, 2:].clone(), fl[:, :2].clone())
             G[0][:, 2] = 1.0
-            t_unpack = None
-        del gathered
+            state["t_unpack"] = None
         train_model = AlphaZeroNet(num_blocks=args.blocks, num_filters=128).to(coll_dev)
         train_model.load_state_dict(model.state_dict())
         opt = torch.optim.Adam(train_model.parameters(), lr=1e-3, weight_decay=1e-4)
         per = max(1, 1024 // world)
         lo = rank * per
-        batch = (G[0][lo:lo + per], G[1][lo:lo + per], G[2][lo:lo + per])
-        del G
-        train_step(train_model, opt, *batch)          # warm-up (allocator, RCCL channels)
+        state.update(train_model=train_model, opt=opt, per=per, batch=(G[0][lo:lo + per], G[1][lo:lo + per], G[2][lo:lo + per]))
+
+    try:
+        from alphazero_amd.distributed import all_gather_packed, train_step
+        if not stage(prepare):
+            return {"error": err}
+        all_gather_packed(state["packed"][:16])       # warm-up (RCCL channels)
         barrier()
         t1 = time.perf_counter()
-        train_step(train_model, opt, *batch)
+        state["gathered"] = all_gather_packed(state["packed"])
+        barrier()
+        t_gather = time.perf_counter() - t1
+        if not stage(unpack):
+            return {"error": err}
+        train_step(state["train_model"], state["opt"], *state["batch"])   # warm-up (allocator, RCCL channels)
+        barrier()
+        t1 = time.perf_counter()
+        train_step(state["train_model"], state["opt"], *state["batch"])
         barrier()
         t_train = time.perf_counter() - t1
         tt = torch.tensor([t_gather, t_train], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        return {"sample_allgather_ms": float(tt[0]) * 1e3, "samples_per_rank": n_s,
-                "bytes_per_rank": n_s * PACKED_SAMPLE_BYTES, "wire_format": "packed rows of 792 B (bitboards | wl | pi f32)",
+        t_unpack = state["t_unpack"]
+        return {"sample_allgather_ms": float(tt[0]) * 1e3, "samples_per_rank": state["n_s"],
+                "bytes_per_rank": state["n_s"] * state["row"], "wire_format": "packed rows of 792 B (bitboards | wl | pi f32)",
                 "unpack_ms": None if t_unpack is None else t_unpack * 1e3,
                 "train_step_ms": float(tt[1]) * 1e3,
-                "train_global_batch": per * world, "backend": backend}
+                "train_global_batch": state["per"] * world, "backend": backend}
     except Exception as exc:  # the self-play line must still be printed
         return {"error": repr(exc)}
 

@@ -257,12 +257,17 @@ int az_engine_stats(az_engine* e, uint64_t* depth_sum_host, uint64_t* descents_h
  */
 typedef struct {
     uint64_t simulations;     /* descents backed up since creation */
-    uint64_t nn_evals;        /* leaves + roots sent to the network */
+    uint64_t nn_evals;        /* leaves + roots that needed an evaluation, whichever API ran the search
+                                 (az_engine_search / az_engine_play_move, or the step calls
+                                 az_engine_roots_prepare ... az_engine_expand_backup) */
     uint64_t moves;           /* plies played */
     uint64_t games_finished;
     uint64_t samples_pending; /* finished-game samples waiting in the queue */
-    uint64_t network_rows;    /* positions the network launches of the fused search actually computed:
-                                 equals nn_evals (terminal leaves and idle games take no row) */
+    uint64_t network_rows;    /* positions the network launches of the fused search (az_engine_search,
+                                 az_engine_play_move) actually computed; terminal leaves and idle games
+                                 take no row, so it equals nn_evals as long as every search of this
+                                 engine ran through those two calls (evaluations the step calls asked the
+                                 caller for count in nn_evals only) */
 } az_selfplay_stats;
 
 int az_engine_attach_net(az_engine* e, az_net* n);

@@ -14,6 +14,7 @@ Outputs (all data, no code):
     nn_tier.npz      float32 logits of seeded AlphaZeroNet instances
     latency_tier.npz   MCTS.search(game, add_noise=False) with a fresh root at 200 simulations, the
                      move arena.py / web.py pick from it, and one whole arena-style game
+    handbuilt_tier.npz  search_batch on roots built by hand (a rebuilt tree; typed-in children)
     baseline_movegen_tier.npz  legal-move sets and terminal results of the reference's second,
                      independently written move generator (src/baseline/state.py)
 """
@@ -706,12 +707,97 @@ def make_baseline_movegen_tier():
     np.savez_compressed(os.path.join(HERE, "baseline_movegen_tier.npz"), **out)
     print("baseline movegen tier:", len(rows), "positions,", int(out["terminal"].sum()), "terminal")
 
+# ------------------------------------------------------------------ hand-built roots
+def flatten_tree(root):
+    """Breadth-first arrays of a Node tree (children of a node contiguous, insertion order)."""
+    nodes, first, count, action = [root], [0], [0], [0]
+    i = 0
+    while i < len(nodes):
+        ch = nodes[i].children
+        if ch:
+            first[i], count[i] = len(nodes), len(ch)
+            for a, c in ch.items():
+                nodes.append(c)
+                first.append(0)
+                count.append(0)
+                action.append(a)
+        i += 1
+    return dict(
+        n=len(nodes), first=np.array(first, np.uint32), count=np.array(count, np.uint8), action=np.array(action, np.uint8),
+        N=np.array([nd.visit_count for nd in nodes], np.uint32),
+        W=np.array([float(nd.value_sum) for nd in nodes], np.float64),
+        P=np.array([float(nd.prior) for nd in nodes], np.float64),
+        # 0: numpy float32, 1: numpy float64, 2: plain Python float
+        ptype=np.array([0 if isinstance(nd.prior, np.float32) else (1 if isinstance(nd.prior, np.float64) else 2)
+                        for nd in nodes], np.uint8))
+
+
+def copy_tree(node):
+    """The same tree in freshly constructed Node objects (what a caller that rebuilds a saved tree holds)."""
+    c = Node(node.prior)
+    c.visit_count, c.value_sum = node.visit_count, node.value_sum
+    for a, ch in node.children.items():
+        c.children[a] = copy_tree(ch)
+    return c
+
+
+def make_handbuilt_tier():
+    """search_batch with roots the caller built by hand (src/mcts.py:117-125 accepts any Node):
+    (a) a searched tree rebuilt node by node and searched on; (b) a root whose children were
+    typed in: a subset of the legal moves in an order of the caller's choosing, float64 priors,
+    preset visit counts and value sums."""
+    pos = tree_positions()
+    cases = []
+    for gi, S1, S2 in ((0, 40, 60), (3, 25, 100), (5, 80, 30), (7, 10, 200)):
+        g = pos[gi]
+        m = TableMCTS(None, num_simulations=S1, c_puct=1.5)
+        root = m.search_batch([g.clone()], None, add_noise=False)[0]
+        rebuilt = copy_tree(root)
+        tree = flatten_tree(rebuilt)
+        m2 = TableMCTS(None, num_simulations=S2, c_puct=1.5)
+        out = m2.search_batch([g.clone()], [rebuilt], add_noise=False)[0]
+        best = max(out.children, key=lambda a: out.children[a].visit_count)
+        cases.append((g, tree, S2, root_stats(out), best, root_stats(out.children[best])))
+    rng = random.Random(5)
+    for gi, S2 in ((1, 50), (4, 120), (6, 64)):
+        g = pos[gi]
+        acts = [g.encode_action(mv) for mv in g.get_legal_moves()]
+        rng.shuffle(acts)
+        acts = acts[: max(2, len(acts) // 2)]
+        wts = np.array([rng.random() + 0.1 for _ in acts])
+        pri = wts / wts.sum()                              # numpy float64 priors
+        root = Node(0)
+        root.visit_count = 7
+        for a, p_ in zip(acts, pri):
+            ch = Node(p_)
+            ch.visit_count = rng.choice((0, 0, 1, 3))
+            ch.value_sum = np.float32(rng.uniform(-1, 1) * ch.visit_count)
+            root.children[a] = ch
+        tree = flatten_tree(root)
+        m2 = TableMCTS(None, num_simulations=S2, c_puct=1.5)
+        out = m2.search_batch([g.clone()], [root], add_noise=False)[0]
+        best = max(out.children, key=lambda a: out.children[a].visit_count)
+        cases.append((g, tree, S2, root_stats(out), best, root_stats(out.children[best])))
+    o = {"n_cases": np.array(len(cases))}
+    for i, (g, tree, S2, st, best, st_best) in enumerate(cases):
+        w, b = game_bits(g)
+        o[f"c{i}_white"], o[f"c{i}_black"], o[f"c{i}_turn"] = np.uint64(w), np.uint64(b), np.int8(g.turn)
+        o[f"c{i}_sims"], o[f"c{i}_best"] = np.array(S2), np.array(best)
+        for k_, v in tree.items():
+            o[f"c{i}_tree_{k_}"] = np.asarray(v)
+        for k_, v in st.items():
+            o[f"c{i}_root_{k_}"] = np.asarray(v)
+        for k_, v in st_best.items():
+            o[f"c{i}_child_{k_}"] = np.asarray(v)
+    np.savez_compressed(os.path.join(HERE, "handbuilt_tier.npz"), **o)
+    print("hand-built tier:", len(cases), "cases,", [c[1]["n"] for c in cases], "nodes")
+
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
     tiers = {"table": make_table, "game": make_game_tier, "tree": make_tree_tier,
              "tree_wide": make_tree_wide_tier, "tree_cpuct": make_tree_cpuct_tier, "tree_deep": make_tree_deep_tier, "probs": make_probs_tier,
              "selfplay": make_selfplay_tier, "selfplay_wide": make_selfplay_wide_tier, "nn": make_nn_tier, "train": make_train_tier,
-             "latency": make_latency_tier, "baseline_movegen": make_baseline_movegen_tier}
+             "latency": make_latency_tier, "baseline_movegen": make_baseline_movegen_tier, "handbuilt": make_handbuilt_tier}
     for name in (sys.argv[1:] or list(tiers)):
         tiers[name]()

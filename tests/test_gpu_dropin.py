@@ -77,6 +77,61 @@ def test_tree_reuse_through_node_handles_matches_reference(golden_dir):
                 alive.remove(i)
 
 
+def _node_from_arrays(d, c):
+    """Plain host Node objects from the breadth-first arrays of handbuilt_tier.npz, with the
+    value types the reference held (prior: numpy float32 / numpy float64 / Python float)."""
+    from alphazero_amd.mcts import Node
+    n = int(d[f"{c}_tree_n"])
+    P, pt = d[f"{c}_tree_P"], d[f"{c}_tree_ptype"]
+    nodes = []
+    for i in range(n):
+        prior = np.float32(P[i]) if pt[i] == 0 else (np.float64(P[i]) if pt[i] == 1 else float(P[i]))
+        nd = Node(prior)
+        nd.visit_count = int(d[f"{c}_tree_N"][i])
+        nd.value_sum = np.float32(d[f"{c}_tree_W"][i]) if nd.visit_count else 0.0
+        nodes.append(nd)
+    for i in range(n):
+        f, k = int(d[f"{c}_tree_first"][i]), int(d[f"{c}_tree_count"][i])
+        for j in range(f, f + k):
+            nodes[i].children[int(d[f"{c}_tree_action"][j])] = nodes[j]
+    return nodes[0]
+
+
+def _check_case(st, d, prefix):
+    k = int(d[f"{prefix}_k"])
+    assert st["root_N"] == int(d[f"{prefix}_root_N"]) and len(st["actions"]) == k
+    assert np.array_equal(st["actions"], d[f"{prefix}_actions"][:k])
+    assert np.array_equal(st["N"], d[f"{prefix}_N"][:k])
+    assert np.array_equal(st["W"].view(np.uint32), d[f"{prefix}_W"][:k].view(np.uint32))
+    assert np.array_equal(st["p_is64"], d[f"{prefix}_p_is64"][:k])
+    assert np.array_equal(st["P"].view(np.uint64), d[f"{prefix}_P"][:k].view(np.uint64))
+
+
+def test_search_from_hand_built_roots_matches_reference(golden_dir):
+    """search_batch takes any Node as a root (src/mcts.py:117-125): a tree the caller rebuilt node
+    by node from an earlier search (up to 1,909 nodes, uniform-fallback nodes among them) and
+    roots with typed-in children (a subset of the legal moves in the caller's order, float64
+    priors, preset statistics).  The host tree is uploaded into an engine slot and searched on;
+    root and most-visited child must report what the reference reported (handbuilt_tier.npz),
+    and the caller's own Node objects must show the new statistics."""
+    d = np.load(os.path.join(golden_dir, "handbuilt_tier.npz"))
+    for i in range(int(d["n_cases"])):
+        c = f"c{i}"
+        game = _game(d[f"{c}_white"], d[f"{c}_black"], d[f"{c}_turn"])
+        root = _node_from_arrays(d, c)
+        held = dict(root.children)                       # the caller's own child objects
+        m = _table_mcts(int(d[f"{c}_sims"]))
+        out = m.search_batch([game], [root], add_noise=False)[0]
+        assert out is root
+        _check_case(_stats(out), d, f"{c}_root")
+        best = int(d[f"{c}_best"])
+        _check_case(_stats(out.children[best]), d, f"{c}_child")
+        assert held[best].visit_count == out.children[best].visit_count
+    # the same object searched again continues the device tree
+    again = m.search_batch([game], [root], add_noise=False)[0]
+    assert again.visit_count == int(d[f"{c}_root_root_N"]) + int(d[f"{c}_sims"])
+
+
 class TestReferenceSemantics:      # tests/test_mcts.py:48-195 with the real (bf16) network
     @pytest.fixture(scope="class")
     def mcts(self):

@@ -233,3 +233,29 @@ def test_learn_reads_a_wrapped_ring_like_a_flat_buffer(tmp_path):
         torch.manual_seed(7)
         tr.learn(epochs=1, batch_size=64)
     assert all(torch.equal(a, b) for a, b in zip(wrapped.model.parameters(), flat.model.parameters()))
+
+
+def test_examples_view_is_lazy_and_mutations_reach_the_buffer():
+    """`trainer.examples` reads like the reference's live list (src/parallel_trainer.py:127):
+    len() copies nothing out of the ring, extend / += append to the ring itself."""
+    from alphazero_amd.parallel_trainer import ParallelTrainer, ExampleArrays
+    from alphazero_amd.model import AlphaZeroNet
+    tr = ParallelTrainer(AlphaZeroNet(num_blocks=1, num_filters=32), device="cpu", num_parallel_games=2,
+                         num_simulations=2, verbose=False)
+    tr.max_examples = 50
+    rs = np.random.RandomState(0)
+
+    def some(n):
+        return ExampleArrays(rs.rand(n, 3, 8, 8).astype(np.float32), rs.rand(n, 192).astype(np.float32),
+                             rs.rand(n, 2).astype(np.float32))
+    a, b, c = some(20), some(10), some(30)
+    tr.add_examples(a)
+    view = tr.examples
+    assert len(view) == 20 and view._np is None and view._t is None          # nothing was copied for len()
+    view.extend(b)
+    assert len(tr.examples) == 30 and len(tr._replay) == 30
+    tr.examples += c                                                          # 60 appended in all, cap 50
+    assert len(tr.examples) == 50 and len(tr._replay) == 50
+    want = np.concatenate([a.policies, b.policies, c.policies])[-50:]
+    assert np.array_equal(tr.examples.policies, want)
+    assert np.array_equal(tr.examples[0][1], want[0]) and np.array_equal(tr.examples[-1][1], want[-1])
