@@ -71,6 +71,7 @@ _SIGNATURES = {
     "az_engine_advance": [_VP, _VP, _VP],
     "az_engine_set_root": [_VP, C.c_int32, C.c_int64, _VP],
     "az_engine_set_roots": [_VP, C.c_int32, _VP, _VP, _VP],
+    "az_engine_search_leaf_parallel": [_VP, C.c_int32, _VP, C.c_int32, C.c_int32, _VP],
     "az_engine_import_tree": [_VP, C.c_int32, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP],
     "az_engine_pool_usage": [_VP, _VP, _VP],
     "az_engine_stats": [_VP, _VP, _VP, _VP],

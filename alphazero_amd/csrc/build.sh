@@ -12,6 +12,7 @@ pids=()
 $HIPCC $COMMON -ffp-contract=off -c tree.hip -o $OBJ/tree.o & pids+=($!)
 $HIPCC $COMMON -ffp-contract=off -c movegen.hip -o $OBJ/movegen.o & pids+=($!)
 $HIPCC $COMMON -ffp-contract=off -c selfplay.hip -o $OBJ/selfplay.o & pids+=($!)
+$HIPCC $COMMON -ffp-contract=off -c leafpar.hip -o $OBJ/leafpar.o & pids+=($!)
 # net: accumulators in architectural VGPRs (no v_accvgpr_read per element in the epilogues)
 $HIPCC $COMMON -mllvm -amdgpu-mfma-vgpr-form=1 -DAZ_SPLIT_STAMPS=${AZ_SPLIT_STAMPS:-0} -c net.hip -o $OBJ/net.o & pids+=($!)
 $HIPCC $COMMON -mllvm -amdgpu-mfma-vgpr-form=1 -Rpass-analysis=kernel-resource-usage -c tower16.hip -o $OBJ/tower16.o 2> $OBJ/tower16.remarks & pids+=($!)

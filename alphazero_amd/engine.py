@@ -270,6 +270,13 @@ class Engine:
         self._call("az_engine_attach_net", self.h, inference.h)
         self.net = inference
 
+    def search_leaf_parallel(self, slots, num_simulations, leaf_batch):
+        """num_simulations simulations of the games in `slots`, leaf_batch descents per network call
+        with virtual loss (az_engine_search_leaf_parallel; results differ from search())."""
+        slots = np.ascontiguousarray(slots, np.int32)
+        self._call("az_engine_search_leaf_parallel", self.h, len(slots), _host_ptr(slots), int(num_simulations),
+                   int(leaf_batch), _stream(self.device))
+
     def search(self, num_simulations, add_noise=False):
         self._call("az_engine_search", self.h, int(num_simulations), int(bool(add_noise)), _stream(self.device))
 

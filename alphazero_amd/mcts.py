@@ -221,7 +221,16 @@ class MCTS:
     """Drop-in for src/mcts.py:43-342."""
 
     def __init__(self, model, num_simulations: int = Config.MCTS_SIMULATIONS, c_puct: float = Config.C_PUCT,
-                 fpu_reduction: float = Config.FPU_REDUCTION, device: str = "cpu"):
+                 fpu_reduction: float = Config.FPU_REDUCTION, device: str = "cpu", leaf_batch: int = 1):
+        """leaf_batch (no counterpart in the reference): descents of a game per network call.  1 is
+        the reference's search, bit for bit.  k > 1 evaluates k leaves of a game at once (virtual
+        loss keeps the descents apart): the search of ONE game, as arena and web run it
+        (src/arena.py:248-265, src/web.py:447-470), then takes a fraction of the time, but visit
+        counts are no longer the reference's.  Needs the HIP network path (an AlphaZeroNet the
+        kernels support, on a GPU)."""
+        if not 1 <= int(leaf_batch) <= 32:
+            raise ValueError("leaf_batch must be in 1..32")
+        self.leaf_batch = int(leaf_batch)
         self.model = model
         self.num_simulations = num_simulations
         self.c_puct = c_puct
@@ -324,7 +333,7 @@ class MCTS:
             return None
         key = tuple(t._version for t in list(m.parameters()) + list(m.buffers()))
         if self._hip is None or self._hip.max_batch < engine.n:
-            self._hip = HipInference(m, max_batch=max(engine.n, 64), device=engine.device.index)
+            self._hip = HipInference(m, max_batch=max(engine.n, 256 if self.leaf_batch > 1 else 64), device=engine.device.index)
             self._hip_key = key
         elif key != self._hip_key:
             self._hip.refresh()
@@ -404,7 +413,13 @@ class MCTS:
         hip = self._hip_inference(engine)
         if noise is not None:
             engine.add_noise(noise)
-        if hip is not None:
+        if self.leaf_batch > 1:
+            if hip is None:
+                raise _lib.AzError("leaf_batch > 1 needs the HIP network path (a supported AlphaZeroNet on a GPU device)")
+            per_call = max(1, 256 // self.leaf_batch)         # games per call: rows = games x leaf_batch <= 256
+            for lo in range(0, len(slots), per_call):
+                engine.search_leaf_parallel(slots[lo:lo + per_call], self.num_simulations, self.leaf_batch)
+        elif hip is not None:
             engine.search(self.num_simulations, add_noise=False)
         else:
             for _ in range(self.num_simulations):

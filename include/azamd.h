@@ -274,6 +274,18 @@ int az_engine_attach_net(az_engine* e, az_net* n);
 /* One MCTS.search_batch call (src/mcts.py:94-189): expand missing roots,
  * optional device-drawn Dirichlet noise, num_simulations simulations. */
 int az_engine_search(az_engine* e, int32_t num_simulations, int32_t add_noise, void* stream);
+/* Latency mode of MCTS.search (one game at a time, src/arena.py:248-265, src/web.py:447-470):
+ * num_simulations simulations of the n games slots_host[0..n), leaf_batch descents of a game per
+ * network call instead of the reference's one (src/mcts.py:153-187).  Descents whose evaluation
+ * is pending count as one visit with a lost outcome on every node of their path (virtual loss)
+ * until they are backed up; two descents of a batch that reach the same leaf share its
+ * evaluation.  Visit counts and value sums stay exact sums, but the order of the descents is
+ * not the reference's: results differ from az_engine_search for leaf_batch > 1 (use that call
+ * for the reference's results).  Roots must exist (az_engine_search with 0 simulations expands
+ * them).  n * leaf_batch <= 256 rows, leaf_batch <= 32; the attached network must take that
+ * many rows.  No counterpart in the reference. */
+int az_engine_search_leaf_parallel(az_engine* e, int32_t n, const int32_t* slots_host, int32_t num_simulations,
+                                   int32_t leaf_batch, void* stream);
 /* One iteration of the self-play loop (src/parallel_trainer.py:158-217) for
  * every active game: search, visit-count policy with the temperature schedule,
  * record (state, pi, turn), choose the move (actions_host[g] if given, else a

@@ -132,6 +132,52 @@ def test_search_from_hand_built_roots_matches_reference(golden_dir):
     assert again.visit_count == int(d[f"{c}_root_root_N"]) + int(d[f"{c}_sims"])
 
 
+def test_leaf_parallel_search_keeps_the_tree_consistent(golden_dir):
+    """MCTS(leaf_batch=k): k descents of a game per network call with virtual loss (the latency
+    mode for arena / web style single-game searches).  Not the reference's visit counts by
+    construction; what must hold: leaf_batch=1 is the exact search; for k > 1 every tree is a
+    consistent search tree (root visits = simulations, child visits sum to them, children are the
+    legal moves in insertion order, every in-flight count is back to zero, so a second search on
+    the same root adds exactly its simulations), and the chosen move mostly agrees with the exact
+    search on the ten roots of latency_tier.npz."""
+    from alphazero_amd.model import AlphaZeroNet
+    from alphazero_amd.mcts import MCTS
+    d = np.load(os.path.join(golden_dir, "latency_tier.npz"))
+    torch.manual_seed(0)
+    model = AlphaZeroNet(num_blocks=20, num_filters=128).cuda().eval()
+    games = [_game(d["white"][g], d["black"][g], d["turn"][g]) for g in range(len(d["white"]))]
+    S = 200
+
+    def best(root):
+        acts = list(root.children.keys())
+        return acts[int(np.argmax([root.children[a].visit_count for a in acts]))]
+
+    exact = [best(MCTS(model, num_simulations=S, device="cuda").search(g.clone())) for g in games]
+    for k in (8, 16):
+        m = MCTS(model, num_simulations=S, device="cuda", leaf_batch=k)
+        agree = 0
+        for gi, g in enumerate(games):
+            root = m.search(g.clone(), add_noise=False)
+            acts = [g.encode_action(mv) for mv in g.get_legal_moves()]
+            assert list(root.children.keys()) == acts
+            assert root.visit_count == S
+            assert sum(c.visit_count for c in root.children.values()) == S
+            for c in root.children.values():                 # a child's visits = 1 (its own evaluation) + its children's
+                if c.visit_count > 0 and c.is_expanded():
+                    assert sum(x.visit_count for x in c.children.values()) == c.visit_count - 1
+            agree += best(root) == exact[gi]
+            if gi == 0:
+                again = m.search(g.clone(), root=root, add_noise=False)
+                assert again.visit_count == 2 * S and sum(c.visit_count for c in again.children.values()) == 2 * S
+        print(f"leaf_batch {k}: most-visited move equals the exact search's on {agree} of {len(games)} roots")
+        assert agree >= 6
+    # a batch of games in one call, and more simulations than a multiple of the batch
+    m = MCTS(model, num_simulations=37, device="cuda", leaf_batch=8)
+    roots = m.search_batch([g.clone() for g in games], None, add_noise=True)
+    for r in roots:
+        assert r.visit_count == 37 and sum(c.visit_count for c in r.children.values()) == 37
+
+
 class TestReferenceSemantics:      # tests/test_mcts.py:48-195 with the real (bf16) network
     @pytest.fixture(scope="class")
     def mcts(self):

@@ -3,7 +3,7 @@
 #   bash tools/profile_pmc.sh <tag>
 # Every counter pass is its own run (kernel-trace/stats never combined with --pmc).
 set -u
-TAG=${1:-r01}
+TAG=${1:-r03}
 OUT=gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -13,7 +13,7 @@ run_pass() {  # name, counters..., then -- command
   while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done; shift
   timeout -s KILL 120 rocprofv3 --pmc "${ctrs[@]}" --output-format csv -d $OUT/$name -- "$@" > $OUT/$name.log 2>&1 || { echo "pass $name failed"; return 1; }
 }
-NET="python3 tools/net_bench.py --batch 1024 --iters 20"
+NET="python3 tools/net_bench.py --batch 1024 --iters 20"   # AZ_TOWER_FORM in the environment picks the tower kernel
 MOV="python3 tools/movegen_bench.py --n 16000000 --iters 10"
 run_pass tower_fetch FETCH_SIZE -- $NET || exit 1
 run_pass tower_write WRITE_SIZE -- $NET || exit 1

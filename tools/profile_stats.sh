@@ -3,7 +3,7 @@
 # box from the repo root:   bash tools/profile_stats.sh <tag>
 # Leaves <tag>_<workload>_kernel_stats.csv (and the bench line of the self-play run) in gpurun_out/.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -17,6 +17,7 @@ stats() {  # name, then the command
   tail -2 $OUT/$name.log
 }
 stats selfplay python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-secondary || exit 1
+AZ_TOWER_FORM=4 stats selfplay_form4 python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-secondary || exit 1
 stats movegen_1M python3 tools/movegen_bench.py --n 1000000 --iters 200 || exit 1
 stats movegen_64M python3 tools/movegen_bench.py --n 64000000 --iters 20 || exit 1
 stats forward_4096 python3 tools/net_bench.py --batch 4096 --iters 30 || exit 1

@@ -1,6 +1,11 @@
 """How much of the training step's time is launch overhead?  Times the reference's step
-(forward, soft-target losses, backward, clip, Adam) at batch 1024 on the 20x128 network eagerly
-and replayed from one captured HIP graph (static input buffers, capturable Adam)."""
+(forward, soft-target losses, backward, clip, Adam) on the 20x128 network eagerly and replayed
+from one captured HIP graph (static input buffers, capturable Adam), at the reference's batch
+of 1024 (--batch 1024) or at a rank's slice of it (--batch 128: 1024 over 8 data-parallel ranks).
+
+    python tools/train_graph_probe.py --batch 128
+"""
+import argparse
 import os
 import sys
 import time
@@ -11,7 +16,9 @@ import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from alphazero_amd.model import AlphaZeroNet  # noqa: E402
 
-B = 1024
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=1024)
+B = ap.parse_args().batch
 torch.manual_seed(0)
 dev = torch.device("cuda")
 x = (torch.rand((B, 3, 8, 8), device=dev) > 0.7).float()
@@ -65,5 +72,5 @@ for autocast in (False, True):
         g.replay()
     torch.cuda.synchronize()
     graph = (time.perf_counter() - t0) / 30
-    print(f"autocast={autocast}: eager {eager * 1e3:.1f} ms/step ({1 / eager:.1f} steps/s), graph replay {graph * 1e3:.1f} ms/step "
+    print(f"batch {B} autocast={autocast}: eager {eager * 1e3:.1f} ms/step ({1 / eager:.1f} steps/s), graph replay {graph * 1e3:.1f} ms/step "
           f"({1 / graph:.1f} steps/s), loss {float(loss):.3f}", flush=True)
