@@ -327,7 +327,7 @@ class ParallelTrainer:
                  num_parallel_games: int = Config.PARALLEL_GAMES,
                  num_simulations: int = Config.MCTS_SIMULATIONS,
                  checkpoint_dir: str = Config.CHECKPOINT_DIR, seed: int = 0, verbose: bool = True,
-                 autocast_dtype=None):
+                 autocast_dtype=None, graph_step: bool = False):
         self.model = model
         self.device = device
         self.num_parallel_games = num_parallel_games
@@ -343,6 +343,10 @@ class ParallelTrainer:
         self.seed = seed
         self.verbose = verbose
         self.autocast_dtype = autocast_dtype   # None: the reference's float32 step; torch.bfloat16: autocast forward
+        # replay every full batch of learn() from captured HIP graphs (distributed.GraphedTrainStep):
+        # worth it where a step is bound by its launches, i.e. at a data-parallel rank's slice
+        self.graph_step = bool(graph_step)
+        self._graphed = {}                     # slice size -> GraphedTrainStep
         self._selfplay = None          # fused device self-play, built on first use
         self._selfplay_key = None      # version counters of the weights its HIP copy was made from
         os.makedirs(self.checkpoint_dir, exist_ok=True)
@@ -480,26 +484,50 @@ class ParallelTrainer:
             world, rank = dist.get_world_size(), dist.get_rank()
         self._say(f"Training on {2 * n} examples (augmented), LR: {self.optimizer.param_groups[0]['lr']:.6f}")
         stats = None
+        use_graph = self.graph_step and dev.type == "cuda"
         for _ in range(epochs):
-            tot = np.zeros(3)
+            tot = torch.zeros(3, dtype=torch.float32, device=dev)     # summed on the device: one host read per epoch
+            for g in self._graphed.values():
+                g.sums.zero_()
             count = 0
             for idx in index_batches:
                 global_batch = len(idx)
                 if world > 1:
                     idx = idx[rank::world]
                 s, p, w = gather_batch(states, policies, wls, idx.to(dev), perm, n=n, physical=ring.physical)
-                tot += azdist.train_step(self.model, self.optimizer, s, p, w, autocast_dtype=self.autocast_dtype,
-                                         global_batch=global_batch)
+                if use_graph and global_batch == batch_size and len(idx) > 0:
+                    step = self._graphed.get(len(idx))
+                    if step is None:
+                        step = self._graphed[len(idx)] = azdist.GraphedTrainStep(
+                            self.model, self.optimizer, len(idx), autocast_dtype=self.autocast_dtype)
+                    step(s, p, w, global_batch=global_batch)
+                else:
+                    tot += azdist.train_step(self.model, self.optimizer, s, p, w, autocast_dtype=self.autocast_dtype,
+                                             global_batch=global_batch, as_tensor=True).to(dev)
                 count += 1
-            stats = dict(zip(("loss", "pi", "wl"), (tot / max(count, 1)).tolist()))
+            for g in self._graphed.values():
+                tot += g.sums
+            stats = dict(zip(("loss", "pi", "wl"), (tot.double().cpu().numpy() / max(count, 1)).tolist()))
         self.scheduler.step()
         return stats
 
     # ------------------------------------------------------------------ checkpoints
+    def _optimizer_state(self):
+        """optimizer.state_dict() as the reference's trainer writes and reads it: an optimiser
+        made capturable for the graphed step keeps its step counters on the GPU and says so in
+        its parameter groups, which an Adam on another kind of device refuses to load."""
+        sd = self.optimizer.state_dict()
+        if not any(g.get("capturable") for g in sd["param_groups"]):
+            return sd
+        groups = [dict(g, capturable=False) for g in sd["param_groups"]]
+        state = {k: {n: (v.detach().cpu() if n == "step" and torch.is_tensor(v) else v) for n, v in st.items()}
+                 for k, st in sd["state"].items()}
+        return {"state": state, "param_groups": groups}
+
     def _checkpoint_dict(self):
         return {
             "state_dict": self.model.state_dict(),
-            "optimizer": self.optimizer.state_dict(),
+            "optimizer": self._optimizer_state(),
             "scheduler": self.scheduler.state_dict(),
             "config": {"num_blocks": self.model.num_blocks, "num_filters": self.model.num_filters},
         }
@@ -509,6 +537,7 @@ class ParallelTrainer:
         ck = torch.load(path, map_location=self.device, weights_only=True)
         self.model.load_state_dict(ck["state_dict"])
         self.optimizer.load_state_dict(ck["optimizer"])
+        self._graphed = {}                     # captured graphs hold the optimiser state that was just replaced
         if "scheduler" in ck:
             self.scheduler.load_state_dict(ck["scheduler"])
             self.scheduler.T_max = Config.LR_SCHEDULER_T_MAX   # the code's horizon wins over the file's

@@ -254,3 +254,66 @@ def test_one_iteration_of_the_reference_training_loop(tmp_path):
         assert torch.equal(a, b)
     assert np.array_equal(again.examples.policies, trainer.examples.policies)
     assert len(again.execute_parallel_episodes(num_games=4)) >= 4 * 10    # and it plays on with the restored weights
+
+
+def test_graphed_learn_matches_the_eager_step(tmp_path):
+    """ParallelTrainer(graph_step=True): every full batch of learn() is replayed from captured HIP
+    graphs (the regime of a data-parallel rank's small slice, where the step is launch bound); the
+    ragged last batch and the first steps run eagerly.  Same seeds, same examples as an eager
+    trainer, two learn() calls with a learning-rate change between them.  The two runs cannot
+    agree bit for bit: capturable Adam rounds differently in the seventh digit, MIOpen's
+    weight-gradient kernels are not deterministic, and a pre-activation within that noise of zero
+    flips its ReLU mask, which changes single gradient elements by percents (measured: gradients
+    5 % apart on one element at the second step, weights 1e-7 apart before it).  What must hold:
+    the same losses to 5e-3, and after 52 steps the graphed run no further from eager steps with
+    the same (capturable) Adam than twice the distance that optimiser's rounding alone puts
+    between two eager runs; a checkpoint written by the graphed trainer loads into an eager one on
+    the CPU."""
+    from alphazero_amd.model import AlphaZeroNet
+    from alphazero_amd.parallel_trainer import ExampleArrays, ParallelTrainer
+    rs = np.random.RandomState(3)
+    n = 200
+    states = (rs.rand(n, 3, 8, 8) > 0.7).astype(np.float32)
+    pol = rs.rand(n, 192).astype(np.float32)
+    pol /= pol.sum(1, keepdims=True)
+    wls = np.tile(np.array([[1.0, 0.0], [0.0, 1.0]], np.float32), (n // 2, 1))
+
+    def run(graph, capturable=False):
+        torch.manual_seed(11)
+        model = AlphaZeroNet(num_blocks=2, num_filters=32).cuda()
+        tr = ParallelTrainer(model, device="cuda", checkpoint_dir=str(tmp_path / ("g" if graph else "e")), verbose=False,
+                             graph_step=graph)
+        if capturable:
+            from alphazero_amd.distributed import make_capturable
+            make_capturable(tr.optimizer)
+        tr.add_examples(ExampleArrays(states, pol, wls))
+        out = []
+        for _ in range(2):
+            torch.manual_seed(5)
+            out.append(tr.learn(epochs=2, batch_size=32))      # 400 augmented examples: 12 full batches + one of 16
+        return tr, out
+
+    eager, stats_e = run(False)
+    same_adam, _ = run(False, capturable=True)        # eager steps with the optimiser arithmetic the graphs use
+    graphed, stats_g = run(True)
+    assert graphed._graphed and all(g.graph_a is not None for g in graphed._graphed.values())
+    for a, b in zip(stats_e, stats_g):
+        for k in ("loss", "pi", "wl"):
+            assert abs(a[k] - b[k]) < 5e-3, (k, a[k], b[k])
+    def distance(x, y):
+        px = torch.cat([t.float().reshape(-1) for t in x.model.parameters()])
+        py = torch.cat([t.float().reshape(-1) for t in y.model.parameters()])
+        return float((px - py).norm() / px.norm()), float((px - py).abs().max())
+    d_graph, d_adam = distance(same_adam, graphed), distance(eager, same_adam)
+    print(f"after 52 steps, relative L2 distance / largest single difference of the weights: graphed against eager steps "
+          f"with the same optimiser arithmetic {d_graph[0]:.2e} / {d_graph[1]:.2e}; those against the reference's Adam "
+          f"{d_adam[0]:.2e} / {d_adam[1]:.2e}")
+    # replaying the step from graphs must not move the weights further from the eager run than the
+    # optimiser's own rounding does (both are the same chaotic divergence), with a floor for runs
+    # in which no mask happened to flip
+    assert d_graph[0] <= max(2e-3, 2.0 * d_adam[0])
+    graphed.save_iteration_checkpoint(1)
+    other = ParallelTrainer(AlphaZeroNet(num_blocks=2, num_filters=32), device="cpu", checkpoint_dir=str(tmp_path / "g"),
+                            verbose=False)
+    assert other.load_iteration_checkpoint(1)
+    assert not any(g.get("capturable") for g in other.optimizer.param_groups)

@@ -21,6 +21,7 @@ ap.add_argument("--blocks", type=int, default=20)
 ap.add_argument("--bf16", action="store_true", help="autocast the forward to bfloat16")
 ap.add_argument("--find", action="store_true", help="let MIOpen time its solvers per layer shape (cudnn.benchmark)")
 ap.add_argument("--channels-last", action="store_true", help="keep weights and activations NHWC")
+ap.add_argument("--graph", action="store_true", help="replay full batches from captured HIP graphs (ParallelTrainer(graph_step=True))")
 a = ap.parse_args()
 torch.backends.cudnn.benchmark = a.find
 rs = np.random.RandomState(0)
@@ -33,7 +34,7 @@ model = AlphaZeroNet(num_blocks=a.blocks, num_filters=128).cuda()
 if a.channels_last:
     model = model.to(memory_format=torch.channels_last)
 tr = ParallelTrainer(model, device="cuda", checkpoint_dir=tempfile.mkdtemp(), verbose=False,
-                     autocast_dtype=torch.bfloat16 if a.bf16 else None)
+                     autocast_dtype=torch.bfloat16 if a.bf16 else None, graph_step=a.graph)
 tr.add_examples(ExampleArrays(states, pol, wls))
 tr.learn(epochs=1, batch_size=a.batch)            # warm-up (MIOpen kernel selection)
 torch.cuda.synchronize()
@@ -42,5 +43,5 @@ stats = tr.learn(epochs=1, batch_size=a.batch)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 steps = -(-2 * a.examples // a.batch)
-print(f"learn(): {2 * a.examples} augmented examples, batch {a.batch}, {a.blocks}x128: {dt:.2f} s, "
+print(f"learn(){' graph' if a.graph else ''}{' bf16' if a.bf16 else ''}: {2 * a.examples} augmented examples, batch {a.batch}, {a.blocks}x128: {dt:.2f} s, "
       f"{steps / dt:.1f} steps/s, {2 * a.examples / dt:.0f} examples/s, loss {stats['loss']:.3f}")
