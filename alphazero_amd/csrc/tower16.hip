@@ -104,7 +104,8 @@ __device__ __forceinline__ void store_act16(char* lds, const uint32_t (&wa)[4], 
         }
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt) {
-            const f32x4 u = acc[2 * t][pt] + b0, v = acc[2 * t + 1][pt] + b1;
+            f32x4 u = acc[2 * t][pt], v = acc[2 * t + 1][pt];
+            if (BIAS) { u += b0; v += b1; }      // (x + 0 is not x for x = -0: the compiler would keep the adds)
             uint4 o = make_uint4(pack_bf16x2(u[0], u[1]), pack_bf16x2(u[2], u[3]), pack_bf16x2(v[0], v[1]),
                                  pack_bf16x2(v[2], v[3]));
             if (RELU) { o.x = relu_bf16x2(o.x); o.y = relu_bf16x2(o.y); o.z = relu_bf16x2(o.z); o.w = relu_bf16x2(o.w); }
@@ -350,35 +351,40 @@ __global__ __launch_bounds__(256, 1) void k_tower16(TowerParams p) {
                 continue;
             }
             // Squeeze: per-channel mean of z (= acc, bias included) over the 64 pixels.  A lane sums
-            // its four pixel tiles, then the 32 per-lane sums (8 tiles x 4 channels) are
-            // reduce-scattered over the 16 lanes of the DPP row that holds the same channels:
-            // lane c ends with the totals of sums 2c and 2c + 1.
-            {
-                float v[32];
+            // its four pixel tiles; the per-lane sums are then all-reduced over the 16 lanes of the
+            // DPP row that holds the same channels: four rotate-and-add steps (row_ror 8, 4, 2, 1),
+            // each ONE v_add_f32 with a DPP operand.  Two tiles (8 channels, 8 independent chains) at
+            // a time; lane 0 of each row stores the row's means.
+            // (volatile asm keeps the step-major order inside a group: left to the compiler, one
+            // chain's four dependent steps run back to back and the squeeze is bound by their
+            // latency.  Seven independent adds lie between a write and the DPP read of it; the
+            // s_nop covers the first step's operands.)
+#define AZ_DPP_STEP(ROR)                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                          \
+        asm volatile("v_add_f32_dpp %0, %0, %0 row_ror:" #ROR " row_mask:0xf bank_mask:0xf" : "+v"(v[i]));
 #pragma unroll
-                for (int nt = 0; nt < 8; ++nt) {
+            for (int g = 0; g < 4; ++g) {
+                float v[8];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int nt = g * 2 + h;
                     const f32x4 s4 = (acc[nt][0] + acc[nt][1]) + (acc[nt][2] + acc[nt][3]);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[nt * 4 + i] = s4[i];
+                    for (int i = 0; i < 4; ++i) v[h * 4 + i] = s4[i];
                 }
-#pragma unroll
-                for (int step = 0; step < 4; ++step) {
-                    const int half = 16 >> step;   // values kept
-                    const int dist = 8 >> step;    // exchange distance in lanes
-                    const bool up = (c & dist) != 0;
-#pragma unroll
-                    for (int i = 0; i < half; ++i) {
-                        float a = v[i], bq = v[i + half];
-                        asm("" : "+v"(a));
-                        const float send = up ? a : bq;
-                        const float keepv = up ? bq : a;
-                        v[i] = keepv + lane_xor(send, dist);
-                    }
+                asm volatile("s_nop 1");
+                AZ_DPP_STEP(8)
+                AZ_DPP_STEP(4)
+                AZ_DPP_STEP(2)
+                AZ_DPP_STEP(1)
+                if (c == 0) {
+                    const f32x4 m0 = {v[0] * (1.0f / 64.0f), v[1] * (1.0f / 64.0f), v[2] * (1.0f / 64.0f), v[3] * (1.0f / 64.0f)};
+                    const f32x4 m1 = {v[4] * (1.0f / 64.0f), v[5] * (1.0f / 64.0f), v[6] * (1.0f / 64.0f), v[7] * (1.0f / 64.0f)};
+                    *reinterpret_cast<f32x4*>(scratch + g * 32 + q * 8) = m0;
+                    *reinterpret_cast<f32x4*>(scratch + g * 32 + q * 8 + 4) = m1;
                 }
-                // sums 2c, 2c + 1: tile c >> 1, channels (c & 1) * 2 + {0, 1} of the quad
-                const int ch0 = (c >> 2) * 32 + q * 8 + (c & 3) * 2;
-                *reinterpret_cast<float2*>(scratch + ch0) = make_float2(v[0] * (1.0f / 64.0f), v[1] * (1.0f / 64.0f));
             }
+#undef AZ_DPP_STEP
             wave_lds_sync();
             const unsigned long long tsa = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
             // fc1 (128 -> 16) + ReLU: lane = (j = lane & 15, quarter = lane >> 4)

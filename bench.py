@@ -124,21 +124,26 @@ def cpu_worker(games, sims, blocks, seconds, seed):
                       "seconds": time.perf_counter() - t0}), flush=True)
 
 
-def host_cores():
+def host_cores(world=1):
     """Cores this job may use: the affinity mask, capped by the pool's per-job share when the
     environment states one (OMP_NUM_THREADS is set to it on the GPU boxes, where the
-    affinity mask still shows the whole machine)."""
+    affinity mask still shows the whole machine).  torch.distributed.run sets OMP_NUM_THREADS=1
+    for its workers when nobody else set it: that is no statement about the job's share, and the
+    cap is then the boxes' 16 cores per GPU."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     share = os.environ.get("OMP_NUM_THREADS", "")
-    if share.isdigit() and int(share) > 0:
+    injected = share == "1" and "TORCHELASTIC_RUN_ID" in os.environ
+    if injected:
+        n = min(n, 16 * max(1, world))
+    elif share.isdigit() and int(share) > 0:
         n = min(n, int(share))
     return max(1, n)
 
 
-def cpu_baseline(sims, blocks, seconds, games=128, procs=None):
+def cpu_baseline(sims, blocks, seconds, games=128, procs=None, world=1):
     """P = host cores independent processes x 128 games, one torch thread each.  Runs before
     this process touches the GPU."""
-    P = procs or host_cores()
+    P = procs or host_cores(world)
     env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
     t0 = time.perf_counter()
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(i), "--sims", str(sims),
@@ -322,7 +327,7 @@ def self_launch(args):
     # the CPU leg runs here, on a host that is otherwise idle, before any rank exists
     cpu = None
     if args.cpu_seconds > 0 and not args.exchange_only:
-        cpu = cpu_baseline(args.sims, args.blocks, args.cpu_seconds)
+        cpu = cpu_baseline(args.sims, args.blocks, args.cpu_seconds, world=args.gpus)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
@@ -383,7 +388,7 @@ def main():
     # (N > 1 under a launcher: rank 0 runs it while the other ranks wait in the rendezvous, idle)
     cpu = None
     if rank == 0 and args.cpu_seconds > 0 and not args.exchange_only and not os.environ.get("AZ_BENCH_CPU_LEG_DONE"):
-        cpu = cpu_baseline(args.sims, args.blocks, args.cpu_seconds)
+        cpu = cpu_baseline(args.sims, args.blocks, args.cpu_seconds, world=world)
 
     backend = os.environ.get("AZ_BENCH_BACKEND", "nccl")
     rehearsal = backend != "nccl"

@@ -53,7 +53,7 @@ def one_round(seed, sizes=SIZES, max_sims=48, max_plies=3, verbose=False):
     sims = int(rs.choice([1, 2, 9, max_sims]))
     plies = int(rs.randint(1, max_plies + 1))
     noisy = bool(rs.random() < 0.5)
-    form = int(rs.choice([1, 2, 4, 8]))
+    form = int(rs.choice([1, 2, 4, 8, 16]))
     inf = _inference(int(rs.choice([1, 2])))
     inf.set_tower_form(form)
     w, b, t, win = orc.random_positions(3 * n + 8, seed)
