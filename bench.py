@@ -234,7 +234,7 @@ def secondary_block(blocks):
     tower_ms, tower_n = inf.tower_time()
     sec = e0.elapsed_time(e1) * 1e-3 / iters
     flop = network_flop_per_position(blocks) * B
-    out["forward_4096"] = {"kernels": "k_tower + k_head_gemm + k_head_finish", "batch": B, "ms_per_forward": sec * 1e3,
+    out["forward_4096"] = {"kernels": "k_tower16 + k_head_gemm + k_head_finish", "batch": B, "ms_per_forward": sec * 1e3,
                            "positions_per_sec": B / sec, "flop_per_position": network_flop_per_position(blocks),
                            "achieved_TFLOPs": flop / sec / 1e12, "peak_TFLOPs": PEAK_BF16_DENSE / 1e12,
                            "frac": flop / sec / PEAK_BF16_DENSE, "tower_ms": tower_ms, "tower_samples": tower_n,
