@@ -19,6 +19,7 @@ $HIPCC $COMMON -mllvm -amdgpu-mfma-vgpr-form=1 -DAZ_SPLIT_STAMPS=${AZ_SPLIT_STAM
 # accumulators, 96 fragment registers, the packed residual and the tap addresses exceed 256 registers and
 # the allocator moves accumulators in and out of AGPRs inside the tap loop (s_nop 7 after the MFMA each time).
 $HIPCC $COMMON ${T16_FLAGS-} -Rpass-analysis=kernel-resource-usage -c tower16.hip -o $OBJ/tower16.o 2> $OBJ/tower16.remarks & pids+=($!)
+$HIPCC $COMMON -c tower_any.hip -o $OBJ/tower_any.o & pids+=($!)
 g++ -O2 -fPIC -std=c++17 -c core.cpp -o $OBJ/core.o & pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJ/*.o

@@ -1054,6 +1054,48 @@ __global__ __launch_bounds__(256) void k_head_gemm(HeadParams p) {
         head_gemm_body<2, 8>(p.v_act, VALUE_K, p.wv, p.part_v, 128, p.B, c - POLICY_CHUNKS, tile, wave, lane);
 }
 
+// The same GEMMs for a policy FC of any K = 64 * num_filters (k_tower_any's networks): POLICY_CHUNKS
+// chunks of K / POLICY_CHUNKS, so that the partial sums have the shape the finish code reads;
+// plain k-step loop (these networks are small or off the tuned path).
+template <int NTW, int NTILES>
+__device__ __forceinline__ void head_gemm_any_body(const __bf16* act, int K, int kchunk, const uint8_t* w, float* part,
+                                                   int N, int B, int chunk, int tile, int wave, int lane) {
+    const int row = lane & 15, quarter = lane >> 4;
+    const int ks0 = chunk * (kchunk / 32);
+    const __bf16* arow = act + ((size_t)tile * (K / 32) + ks0) * 512 + row * 32 + quarter * 8;
+    const uint8_t* wbase = w + (((size_t)ks0 * NTILES + wave * NTW) * 64 + lane) * 16;
+    f32x4 acc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < kchunk / 32; ++ks) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(arow + (size_t)ks * 512);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(wbase + ((size_t)ks * NTILES + t) * 1024);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int n = (wave * NTW + t) * 16 + (lane & 15);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int pp = tile * 16 + (lane >> 4) * 4 + v;
+            if (pp < B) part[((size_t)chunk * B + pp) * N + n] = acc[t][v];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_head_gemm_any(HeadParams p, int policy_k) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tile = blockIdx.x, c = blockIdx.y;
+    if (p.n_rows && tile * 16 >= *p.n_rows) return;
+    if (c < POLICY_CHUNKS)
+        head_gemm_any_body<3, 12>(p.p_act, policy_k, policy_k / POLICY_CHUNKS, p.wp, p.part_p, NUM_ACTIONS, p.B, c, tile, wave, lane);
+    else
+        head_gemm_any_body<2, 8>(p.v_act, VALUE_K, HEAD_KCHUNK, p.wv, p.part_v, 128, p.B, c - POLICY_CHUNKS, tile, wave, lane);
+}
+
 // one wave per position
 __global__ __launch_bounds__(256) void k_head_finish(FinishParams p) {
     const int lane = threadIdx.x & 63;
@@ -1124,6 +1166,8 @@ static int scratch_address(int device, unsigned char** out) {
 
 struct az_net {
     int blocks = 0, max_batch = 0, device = 0;
+    int ch = CH, se_hid = SE_HID;
+    bool any_width = false;   // not 128 filters with 16 hidden units: k_tower_any + k_head_gemm_any, their own weight images
     bool loaded = false;
     std::vector<void*> allocs;
     uint8_t *stem_w = nullptr, *conv_w = nullptr, *value_w = nullptr, *wp = nullptr, *wv = nullptr;
@@ -1177,6 +1221,7 @@ extern "C" int az_net_max_batch(az_net* n) { return n ? n->max_batch : 0; }
 extern "C" int az_net_set_tower_form(az_net* n, int32_t form) {
     AZ_CHECK_ARG(n, "az_net_set_tower_form: null network");
     AZ_CHECK_ARG(form == 0 || form == 1 || form == 2 || form == 4 || form == 8 || form == 16, "az_net_set_tower_form: form %d is not one of 0, 1, 2, 4, 8, 16", form);
+    AZ_CHECK_ARG(form == 0 || !n->any_width, "az_net_set_tower_form: a %d-filter network with %d hidden units has one tower kernel (form 0)", n->ch, n->se_hid);
     n->tower_form = form;
     return AZ_OK;
 }
@@ -1219,9 +1264,10 @@ extern "C" int az_net_destroy(az_net* n) {
 
 extern "C" int az_net_create(az_net** out, const az_net_config* cfg) {
     AZ_CHECK_ARG(out && cfg, "az_net_create: null argument");
-    AZ_CHECK_ARG(cfg->num_filters == CH, "az_net_create: the HIP path supports num_filters == 128 only (got %d)",
-                 cfg->num_filters);
-    AZ_CHECK_ARG(cfg->se_ratio == 8, "az_net_create: the HIP path supports se_ratio == 8 only (got %d)", cfg->se_ratio);
+    AZ_CHECK_ARG(cfg->num_filters >= 32 && cfg->num_filters <= 256 && cfg->num_filters % 32 == 0,
+                 "az_net_create: num_filters must be a multiple of 32 between 32 and 256 (got %d)", cfg->num_filters);
+    AZ_CHECK_ARG(cfg->se_ratio >= 1 && cfg->se_ratio <= cfg->num_filters,
+                 "az_net_create: se_ratio %d leaves no hidden unit for %d filters", cfg->se_ratio, cfg->num_filters);
     AZ_CHECK_ARG(cfg->num_blocks >= 1 && cfg->num_blocks <= 64, "az_net_create: num_blocks %d out of range", cfg->num_blocks);
     AZ_CHECK_ARG(cfg->max_batch >= 1 && cfg->max_batch <= (1 << 20), "az_net_create: max_batch %d out of range", cfg->max_batch);
     if (cfg->device >= 0) AZ_HIP(hipSetDevice(cfg->device));
@@ -1231,18 +1277,31 @@ extern "C" int az_net_create(az_net** out, const az_net_config* cfg) {
     n->blocks = cfg->num_blocks;
     n->max_batch = cfg->max_batch;
     n->device = device;
+    n->ch = cfg->num_filters;
+    n->se_hid = cfg->num_filters / cfg->se_ratio;   // nn.Linear(channels, channels // se_ratio), src/model.py:33
+    n->any_width = !(n->ch == CH && n->se_hid == SE_HID);
     const size_t nb = n->blocks, nconv = 2 * nb + 1, B = n->max_batch;
+    const size_t Cw = n->ch, Hw = n->se_hid;
     unsigned char* static_buffers = nullptr;
     int rc = scratch_address(device, &static_buffers);   // once per device, while it is current
 #define A(ptr, cnt) if (rc == AZ_OK) rc = dev_alloc(n, n->ptr, (cnt))
-    A(stem_w, 2 * 4 * 64 * 16); A(stem_b, CH);
-    A(conv_w, nconv * CONV_BYTES); A(conv_b, (nconv + 1) * CH);  // + one zero row
-    A(se_img, nb * SE_BYTES);
-    A(stem_w16, 8 * 64 * 16); A(conv_w16, nconv * CONV_BYTES); A(value_w16, 4 * 2 * 64 * 16);
-    A(value_w, 8 * 64 * 16); A(value_b, VALUE_CH);
-    A(wp, (size_t)(POLICY_K / 32) * 12 * 64 * 16); A(bp, NUM_ACTIONS);
+    if (!n->any_width) {
+        A(stem_w, 2 * 4 * 64 * 16);
+        A(conv_w, nconv * CONV_BYTES);
+        A(se_img, nb * SE_BYTES);
+        A(stem_w16, 8 * 64 * 16); A(conv_w16, nconv * CONV_BYTES); A(value_w16, 4 * 2 * 64 * 16);
+        A(value_w, 8 * 64 * 16);
+    } else {   // k_tower_any's images (TowerParams::ch)
+        A(stem_w16, (Cw / 16) * 64 * 16);
+        A(conv_w16, nconv * 9 * (Cw / 32) * (Cw / 16) * 1024);
+        A(se_img, nb * (Hw * Cw + Hw + 2 * Cw * Hw + 2 * Cw) * sizeof(float));
+        A(value_w16, (Cw / 32) * 2 * 64 * 16);
+    }
+    A(stem_b, Cw); A(conv_b, (nconv + 1) * Cw);  // + one zero row
+    A(value_b, VALUE_CH);
+    A(wp, (size_t)(64 * Cw / 32) * 12 * 64 * 16); A(bp, NUM_ACTIONS);
     A(wv, (size_t)(VALUE_K / 32) * 8 * 64 * 16); A(bv1, 128); A(wv2, 256); A(bv2, 2);
-    A(p_act, (size_t)((B + 15) / 16) * 16 * POLICY_K); A(v_act, (size_t)((B + 15) / 16) * 16 * VALUE_K);
+    A(p_act, (size_t)((B + 15) / 16) * 16 * 64 * Cw); A(v_act, (size_t)((B + 15) / 16) * 16 * VALUE_K);
     A(part_p, (size_t)POLICY_CHUNKS * B * NUM_ACTIONS); A(part_v, (size_t)VALUE_CHUNKS * B * 128);
     A(bits_mine, B); A(bits_theirs, B); A(bad, 1);
     if (getenv("AZ_TOWER_STAMPS")) A(stamps, (B + 3) / 4 * 10);
@@ -1299,8 +1358,130 @@ int upload(T* dst, const std::vector<T>& src) {
 }
 }  // namespace
 
+// The state of a network of any supported width -> k_tower_any's / k_head_gemm_any's images.
+// Same tensor order as below (state_dict() order of src/model.py:116-142).
+static int load_state_any(az_net* n, const float* s, int64_t count) {
+    const int nb = n->blocks, C = n->ch, H = n->se_hid, KS = C / 32, NT = C / 16;
+    const int64_t per_bn = 4 * C, conv_floats = (int64_t)C * C * 9, policy_k = 64ll * C;
+    const int64_t per_block = 2 * (conv_floats + per_bn) + (int64_t)H * C + H + 2ll * C * H + 2 * C;
+    const int64_t expect = (int64_t)C * 27 + per_bn + nb * per_block + (conv_floats + per_bn) +
+                           (int64_t)NUM_ACTIONS * policy_k + NUM_ACTIONS + ((int64_t)VALUE_CH * C + 4 * VALUE_CH) +
+                           128ll * VALUE_K + 128 + 256 + 2;
+    AZ_CHECK_ARG(count == expect, "az_net_load_state: got %lld floats, a %d x %d network with %d hidden units has %lld",
+                 (long long)count, nb, C, H, (long long)expect);
+    AZ_HIP(hipSetDevice(n->device));
+    AZ_HIP(hipDeviceSynchronize());   // see az_net_load_state
+    const float* q = s;
+    auto take = [&](int64_t k) { const float* r = q; q += k; return r; };
+    int rc;
+    const size_t conv_u16 = (size_t)9 * KS * NT * 512;   // bf16 elements per conv image
+    // [tap][ks][nt][lane][8]: output channel nt * 16 + (lane & 15), input channel ks * 32 + 8 * (lane >> 4) + j
+    auto pack_conv = [&](const float* w, const std::vector<float>& scale, uint16_t* out) {
+        for (int tap = 0; tap < 9; ++tap)
+            for (int ks = 0; ks < KS; ++ks)
+                for (int nt = 0; nt < NT; ++nt)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int o = nt * 16 + (lane & 15), c = ks * 32 + 8 * (lane >> 4) + j;
+                            out[((((size_t)tap * KS + ks) * NT + nt) * 64 + lane) * 8 + j] =
+                                f32_to_bf16(w[((size_t)o * C + c) * 9 + tap] * scale[o]);
+                        }
+    };
+    {   // stem: one k-step of 32 (k = tap * 3 + plane, 27 used)
+        const float* w = take((int64_t)C * 27);
+        const float *g = take(C), *b = take(C), *m = take(C), *v = take(C);
+        const Folded f = fold_bn(g, b, m, v, C);
+        std::vector<uint16_t> pk((size_t)NT * 64 * 8, 0);
+        for (int nt = 0; nt < NT; ++nt)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 8 * (lane >> 4) + j, o = nt * 16 + (lane & 15);
+                    if (k < 27) pk[((size_t)nt * 64 + lane) * 8 + j] = f32_to_bf16(w[((size_t)o * 3 + k % 3) * 9 + k / 3] * f.scale[o]);
+                }
+        if ((rc = upload((uint16_t*)n->stem_w16, pk))) return rc;
+        if ((rc = upload(n->stem_b, f.bias))) return rc;
+    }
+    std::vector<uint16_t> convs((size_t)(2 * nb + 1) * conv_u16);
+    std::vector<float> conv_b((size_t)(2 * nb + 2) * C, 0.f);
+    std::vector<float> se;
+    for (int blk = 0; blk < nb; ++blk) {
+        for (int half = 0; half < 2; ++half) {
+            const float* w = take(conv_floats);
+            const float *g = take(C), *b = take(C), *m = take(C), *v = take(C);
+            const Folded f = fold_bn(g, b, m, v, C);
+            const int ci = blk * 2 + half;
+            pack_conv(w, f.scale, convs.data() + (size_t)ci * conv_u16);
+            memcpy(&conv_b[(size_t)ci * C], f.bias.data(), C * sizeof(float));
+        }
+        // fc1.weight [H][C], fc1.bias [H], fc2.weight [2C][H], fc2.bias [2C]: the kernel reads them in this order
+        const int64_t se_floats = (int64_t)H * C + H + 2ll * C * H + 2 * C;
+        const float* blob = take(se_floats);
+        se.insert(se.end(), blob, blob + se_floats);
+    }
+    {   // policy head
+        const float* w = take(conv_floats);
+        const float *g = take(C), *b = take(C), *m = take(C), *v = take(C);
+        const Folded f = fold_bn(g, b, m, v, C);
+        pack_conv(w, f.scale, convs.data() + (size_t)(2 * nb) * conv_u16);
+        memcpy(&conv_b[(size_t)(2 * nb) * C], f.bias.data(), C * sizeof(float));
+        const float* fc = take((int64_t)NUM_ACTIONS * policy_k);
+        const float* fb = take(NUM_ACTIONS);
+        // k' = px * C + c  <->  reference flatten index c * 64 + px (src/model.py:168)
+        std::vector<uint16_t> pk((size_t)(policy_k / 32) * 12 * 64 * 8);
+        for (int ks = 0; ks < policy_k / 32; ++ks)
+            for (int nt = 0; nt < 12; ++nt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int o = nt * 16 + (lane & 15), k = ks * 32 + 8 * (lane >> 4) + j;
+                        const int px = k / C, c = k % C;
+                        pk[(((size_t)ks * 12 + nt) * 64 + lane) * 8 + j] = f32_to_bf16(fc[(size_t)o * policy_k + c * 64 + px]);
+                    }
+        if ((rc = upload((uint16_t*)n->wp, pk))) return rc;
+        if ((rc = upload(n->bp, std::vector<float>(fb, fb + NUM_ACTIONS)))) return rc;
+    }
+    {   // value head
+        const float* w = take((int64_t)VALUE_CH * C);
+        const float *g = take(VALUE_CH), *b = take(VALUE_CH), *m = take(VALUE_CH), *v = take(VALUE_CH);
+        const Folded f = fold_bn(g, b, m, v, VALUE_CH);
+        std::vector<uint16_t> pk((size_t)KS * 2 * 64 * 8);   // [ks][nt 2][lane][8], output channel nt * 16 + (lane & 15)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int nt = 0; nt < 2; ++nt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int o = nt * 16 + (lane & 15), c = ks * 32 + 8 * (lane >> 4) + j;
+                        pk[(((size_t)ks * 2 + nt) * 64 + lane) * 8 + j] = f32_to_bf16(w[(size_t)o * C + c] * f.scale[o]);
+                    }
+        if ((rc = upload((uint16_t*)n->value_w16, pk))) return rc;
+        if ((rc = upload(n->value_b, f.bias))) return rc;
+        const float* fc1 = take(128ll * VALUE_K);
+        const float* fb1 = take(128);
+        std::vector<uint16_t> pv((size_t)(VALUE_K / 32) * 8 * 64 * 8);
+        for (int ks = 0; ks < VALUE_K / 32; ++ks)
+            for (int nt = 0; nt < 8; ++nt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int o = nt * 16 + (lane & 15), k = ks * 32 + 8 * (lane >> 4) + j;
+                        const int px = k / VALUE_CH, c = k % VALUE_CH;
+                        pv[(((size_t)ks * 8 + nt) * 64 + lane) * 8 + j] = f32_to_bf16(fc1[(size_t)o * VALUE_K + c * 64 + px]);
+                    }
+        if ((rc = upload((uint16_t*)n->wv, pv))) return rc;
+        if ((rc = upload(n->bv1, std::vector<float>(fb1, fb1 + 128)))) return rc;
+        const float* fc2 = take(256);
+        const float* fb2 = take(2);
+        if ((rc = upload(n->wv2, std::vector<float>(fc2, fc2 + 256)))) return rc;
+        if ((rc = upload(n->bv2, std::vector<float>(fb2, fb2 + 2)))) return rc;
+    }
+    if (q - s != count) AZ_FAIL(AZ_ERR_ARG, "az_net_load_state: internal layout mismatch");
+    if ((rc = upload((uint16_t*)n->conv_w16, convs))) return rc;
+    if ((rc = upload(n->conv_b, conv_b))) return rc;
+    if ((rc = upload(reinterpret_cast<float*>(n->se_img), se))) return rc;
+    n->loaded = true;
+    return AZ_OK;
+}
+
 extern "C" int az_net_load_state(az_net* n, const float* s, int64_t count) {
     AZ_CHECK_ARG(n && s, "az_net_load_state: null argument");
+    if (n->any_width) return load_state_any(n, s, count);
     const int nb = n->blocks;
     const int64_t per_bn = 4 * CH;
     const int64_t per_block = 2 * ((int64_t)CH * CH * 9 + per_bn) + SE_HID * CH + SE_HID + 2 * CH * SE_HID + 2 * CH;
@@ -1473,8 +1654,18 @@ static int forward_partial(az_net* n, int32_t B, const uint64_t* mine_dev, const
     static const int dbg = getenv("AZ_TOWER_DBG") ? atoi(getenv("AZ_TOWER_DBG")) : 0;
     tp.dbg = dbg;
     tp.stamps = B <= n->max_batch ? n->stamps : nullptr;   // the stamp buffer holds max_batch positions' workgroups (the static-buffer entry point takes larger batches)
+    tp.ch = n->ch; tp.se_hid = n->se_hid;
     const bool stamp = n->timing && (n->launches++ % TIMING_STRIDE == 0) && n->ev_used < TIMING_POOL;
     if (stamp) AZ_HIP(hipEventRecord(n->ev0[n->ev_used], s));
+    if (n->any_width) {
+        tp.stem_w = n->stem_w16; tp.conv_w = n->conv_w16; tp.value_w = n->value_w16; tp.stamps = nullptr;
+        launch_tower_any(tp, B, s);
+        if (stamp) AZ_HIP(hipEventRecord(n->ev1[n->ev_used++], s));
+        HeadParams hp{hb.p_act, hb.v_act, n->wp, n->wv, hb.part_p, hb.part_v, B, tp.n_rows};
+        hipLaunchKernelGGL(k_head_gemm_any, dim3((B + 15) / 16, POLICY_CHUNKS + VALUE_CHUNKS), dim3(256), 0, s, hp, 64 * n->ch);
+        AZ_HIP(hipGetLastError());
+        return AZ_OK;
+    }
     // form of the tower: whole positions per wave from 513 positions up (k_tower16; 4 = k_tower, the
     // same tiling on the 32x32x16 MFMA shape), channel-split waves
     // below (az_net_set_tower_form or AZ_TOWER_FORM force one; with stamps on the default is k_tower, whose stamps are always compiled in)
@@ -1555,6 +1746,7 @@ extern "C" int az_net_forward_noalloc(az_net* n, int32_t B, const uint64_t* mine
     AZ_CHECK_ARG(B <= AZ_NET_NOALLOC_MAX_BATCH,
                  "az_net_forward_noalloc: batch %d exceeds the static buffers' %d positions (use az_net_forward)", B,
                  AZ_NET_NOALLOC_MAX_BATCH);
+    AZ_CHECK_ARG(n->ch <= CH, "az_net_forward_noalloc: the static buffers hold the head activations of networks up to %d filters (this one has %d; use az_net_forward)", CH, n->ch);
     unsigned char* base = (n->device >= 0 && n->device < MAX_DEVICES) ? g_scratch_ptr[n->device] : nullptr;
     if (!base) AZ_FAIL(AZ_ERR_STATE, "az_net_forward_noalloc: the static buffers of device %d were never located", n->device);
     HeadBuffers hb;

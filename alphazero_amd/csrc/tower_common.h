@@ -63,6 +63,12 @@ struct TowerParams {
     __bf16* v_act;              // K = 64 px * 32 ch
     int dbg;                    // diagnostic ablation flags (AZ_TOWER_DBG), 0 in production
     unsigned long long* stamps; // diagnostic: [workgroup][10] cycle sums {loop, conv1 epilogue, block epilogue, 100 MHz ticks, squeeze, fc1, fc2, final, first tick, last tick}; NULL in production
+    // k_tower_any only (the other kernels are built for 128 filters and 16 hidden units): filters and
+    // squeeze-excitation hidden units.  Its images: stem_w [nt C/16][lane 64][16 B], conv_w
+    // [conv][tap 9][ks C/32][nt C/16][lane 64][16 B] with output channel nt * 16 + (lane & 15) and input
+    // channel ks * 32 + 8 * (lane >> 4) + j, value_w [ks C/32][nt 2][lane 64][16 B], se_img float32
+    // [block]{W1 [H][C], b1 [H], W2 [2C][H], b2 [2C]}
+    int ch, se_hid;
 };
 
 // two floats -> packed bf16 (round to nearest even) in ONE v_cvt_pk_bf16_f32: the
@@ -255,5 +261,7 @@ __device__ __forceinline__ int assign_rows(const TowerParams& p, int tid, int lp
 
 // k_tower16 (tower16.hip); tp's weight pointers must be the 16x16x32 images
 void launch_tower16(const TowerParams& tp, int B, hipStream_t s);
+// k_tower_any (tower_any.hip); tp's weight pointers must be that kernel's images, tp.ch / tp.se_hid set
+void launch_tower_any(const TowerParams& tp, int B, hipStream_t s);
 
 }  // namespace az

@@ -91,8 +91,12 @@ class AlphaZeroNet(nn.Module):
         return (wl[:, 0] - wl[:, 1]).unsqueeze(1)
 
     def hip_supported(self):
-        return (self.num_filters == 128 and self.num_input_planes == 3 and self.num_actions == 192
-                and self.se_ratio == 8 and self.num_blocks >= 1)
+        """Whether az_net_create takes this architecture: 3 input planes, 192 actions, a multiple of 32
+        filters up to 256 (128 filters with SE ratio 8 run the tuned kernels, every other width
+        k_tower_any), at least one hidden SE unit."""
+        return (self.num_input_planes == 3 and self.num_actions == 192 and self.num_blocks >= 1
+                and self.num_filters % 32 == 0 and 32 <= self.num_filters <= 256
+                and 1 <= self.se_ratio <= self.num_filters)
 
 
 LC0Network = AlphaZeroNet  # src/model.py:199
@@ -111,7 +115,9 @@ class HipInference:
 
     def __init__(self, model, max_batch=4096, device=None):
         if not model.hip_supported():
-            raise _lib.AzError("HIP inference supports 3 input planes, 128 filters, SE ratio 8, 192 actions")
+            raise _lib.AzError("HIP inference supports 3 input planes, 192 actions and a multiple of 32 filters "
+                               f"between 32 and 256 (got {model.num_input_planes} planes, {model.num_actions} actions, "
+                               f"{model.num_filters} filters, SE ratio {model.se_ratio})")
         if not torch.cuda.is_available():
             raise _lib.AzError("HipInference needs a GPU (no CPU fallback exists)")
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)

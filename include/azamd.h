@@ -62,8 +62,10 @@ typedef struct az_net az_net;
 
 typedef struct {
     int32_t num_blocks;   /* src/config.py:26 */
-    int32_t num_filters;  /* src/config.py:27; the HIP path supports 128 */
-    int32_t se_ratio;     /* src/config.py:28; the HIP path supports 8 */
+    int32_t num_filters;  /* src/config.py:27, src/model.py:110: a multiple of 32 from 32 to 256.  128 with se_ratio 8
+                             (the reference's configuration) runs the tuned tower kernels, every other
+                             combination one any-width kernel (k_tower_any) with the same arithmetic */
+    int32_t se_ratio;     /* src/config.py:28, src/model.py:33: hidden units = num_filters / se_ratio (floor), >= 1 */
     int32_t max_batch;
     int32_t device;       /* HIP device ordinal, -1 = current */
 } az_net_config;
@@ -92,7 +94,8 @@ int az_net_forward(az_net* n, int32_t B, const uint64_t* mine_dev, const uint64_
  * which az_net_forward keeps in buffers az_net_create allocated, live here in a static
  * device array inside the library (6.75 MiB on every GPU the library is used on, held
  * until the process ends), so B is limited to AZ_NET_NOALLOC_MAX_BATCH whatever max_batch
- * the network has; a larger B fails with AZ_ERR_ARG.  Inputs, outputs and results are
+ * the network has; a larger B fails with AZ_ERR_ARG, and so does a network of more than 128
+ * filters (its head activations do not fit the array).  Inputs, outputs and results are
  * those of az_net_forward, bit for bit.  Every call on a GPU shares that GPU's array:
  * calls that overlap on one GPU (two streams, two threads, two networks) race.  The
  * network must have been created and loaded beforehand (that is where the weights are
@@ -115,8 +118,10 @@ int az_net_forward_planes(az_net* n, int32_t B, const float* planes_dev, float* 
 int az_net_set_timing(az_net* n, int32_t enable);
 /* Form of the tower kernel: 0 (default) chooses by batch size - one position per
  * workgroup up to 256 positions, two up to 512, one position per wave above; 1, 2, 4
- * force one of these, 8 the eight-wave channel-split form.  Every form computes the
- * same network (src/model.py:144-180); they differ in how a batch spreads over the chip. */
+ * force one of these (4: on v_mfma_f32_32x32x16_bf16; 16: on v_mfma_f32_16x16x32_bf16, the one
+ * position per wave default), 8 the eight-wave channel-split form.  Every form computes the
+ * same network (src/model.py:144-180); they differ in how a batch spreads over the chip.
+ * The forms are variants of the 128-filter kernel: a network of another width takes 0 only. */
 int az_net_set_tower_form(az_net* n, int32_t form);
 int az_net_tower_time(az_net* n, double* mean_ms, int64_t* samples);
 /* Measurement aid (no reference counterpart): with AZ_TOWER_STAMPS=1 in the environment at

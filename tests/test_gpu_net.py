@@ -32,7 +32,7 @@ def _positions(n, seed):
     return planes
 
 
-def _compare(model, planes, min_top1=0.99):
+def _compare(model, planes, min_top1=0.99, ties=None):
     from alphazero_amd.model import HipInference
     model.eval()
     x = torch.from_numpy(planes)
@@ -52,6 +52,13 @@ def _compare(model, planes, min_top1=0.99):
     print(f"max|dprobs|={err_p:.2e} max|dvalue|={err_v:.2e} max|dlogit|={err_l:.2e} top1={top1:.4f}")
     assert np.allclose(probs.sum(1), 1.0, atol=1e-4)
     assert err_p <= TOL and err_v <= TOL
+    if ties is not None:
+        # small random networks give nearly flat policies: where the best move differs, the float32
+        # forward itself must rate the two moves within `ties` of each other
+        rows = np.nonzero(probs.argmax(1) != probs_ref.argmax(1))[0]
+        gap = probs_ref[rows, probs_ref[rows].argmax(1)] - probs_ref[rows, probs[rows].argmax(1)]
+        assert gap.size == 0 or gap.max() <= ties, gap.max()
+        assert err_l <= 1e-2
     assert top1 >= min_top1
     return inf
 
@@ -192,6 +199,70 @@ def test_matches_reference_logits_fixture(golden_dir):
     assert np.abs(value.cpu().numpy() - (ref_wl[:, 0] - ref_wl[:, 1])).max() <= TOL
 
 
+@pytest.mark.parametrize("filters,ratio,blocks", [(32, 8, 2), (64, 4, 3), (96, 8, 1), (128, 4, 2), (160, 16, 1),
+                                                  (256, 8, 2), (32, 32, 1), (64, 1, 1)])
+def test_other_widths_match_fp32_torch(filters, ratio, blocks):
+    """Widths other than 128 filters / 16 hidden units run k_tower_any + k_head_gemm_any
+    (src/model.py:107-114 takes any num_filters and se_ratio; the reference's own tests build 2 x 32
+    networks): same tolerance against the float32 torch forward, the same bits on every call, and
+    rows that do not depend on the rest of the batch."""
+    from alphazero_amd.model import AlphaZeroNet
+    torch.manual_seed(filters + ratio)
+    model = AlphaZeroNet(num_blocks=blocks, num_filters=filters, se_ratio=ratio)
+    randomize_bn(model, 2)
+    planes = _positions(300, seed=filters)
+    inf = _compare(model, planes, min_top1=0.95, ties=2e-3)
+    x = torch.from_numpy(planes).cuda()
+    p0, v0, _, _ = inf.forward_planes(x)
+    p0, v0 = p0.clone(), v0.clone()
+    for _ in range(5):
+        p, v, _, _ = inf.forward_planes(x)
+        assert torch.equal(p, p0) and torch.equal(v, v0)
+    sub = torch.arange(7, 300, 3, device="cuda")
+    p, v, _, _ = inf.forward_planes(x[sub].contiguous())
+    assert torch.equal(p, p0[sub]) and torch.equal(v, v0[sub])
+    from alphazero_amd._lib import AzError
+    with pytest.raises(AzError):
+        inf.set_tower_form(4)          # the forms are variants of the 128-filter kernel
+    if filters > 128:
+        with pytest.raises(AzError):   # the static head buffers are sized for 128 filters
+            inf.forward_bits_into(torch.zeros(4, dtype=torch.int64, device="cuda"), torch.zeros(4, dtype=torch.int64, device="cuda"),
+                                  torch.empty(4, 192, device="cuda"), torch.empty(4, device="cuda"))
+
+
+def test_small_network_matches_reference_logits_fixture(golden_dir):
+    """nn_tier.npz's `small` logits come from the reference's own 2 x 32 AlphaZeroNet
+    (torch.manual_seed(0), BatchNorm statistics randomised with seed 1): the network of the
+    reference's tests (tests/test_mcts.py:54) on the HIP path."""
+    from alphazero_amd.model import AlphaZeroNet, HipInference
+    d = np.load(os.path.join(golden_dir, "nn_tier.npz"))
+    n = len(d["sel"])
+    planes = np.unpackbits(d["planes"])[: n * 192].reshape(n, 3, 8, 8).astype(np.float32)
+    torch.manual_seed(0)
+    model = AlphaZeroNet(num_blocks=2, num_filters=32)
+    randomize_bn(model, 1)
+    model.eval()
+    with torch.no_grad():
+        pl, wl = model(torch.from_numpy(planes))
+    assert np.allclose(pl.numpy(), d["small_policy_logits"], atol=1e-4)
+    assert np.allclose(wl.numpy(), d["small_wl_logits"], atol=1e-4)
+    inf = HipInference(model, max_batch=64)
+    probs, value, pl_d, _ = inf.forward_planes(torch.from_numpy(planes).cuda(), want_logits=True)
+    ref_p = torch.softmax(torch.from_numpy(d["small_policy_logits"]), 1).numpy()
+    ref_wl = torch.softmax(torch.from_numpy(d["small_wl_logits"]), 1).numpy()
+    assert np.abs(probs.cpu().numpy() - ref_p).max() <= TOL
+    assert np.abs(value.cpu().numpy() - (ref_wl[:, 0] - ref_wl[:, 1])).max() <= TOL
+    # no-allocation entry point: same bits
+    x = torch.from_numpy(planes).cuda()
+    w = (2 ** torch.arange(63, device="cuda", dtype=torch.int64))
+    flat_m, flat_t = x[:, 0].reshape(n, 64).long(), x[:, 1].reshape(n, 64).long()
+    bits_m = (flat_m[:, :63] * w).sum(1) + torch.where(flat_m[:, 63] > 0, torch.tensor(-2 ** 63, device="cuda"), torch.tensor(0, device="cuda"))
+    bits_t = (flat_t[:, :63] * w).sum(1) + torch.where(flat_t[:, 63] > 0, torch.tensor(-2 ** 63, device="cuda"), torch.tensor(0, device="cuda"))
+    p2, v2 = torch.empty(n, 192, device="cuda"), torch.empty(n, device="cuda")
+    inf.forward_bits_into(bits_m.contiguous(), bits_t.contiguous(), p2, v2)
+    assert torch.equal(p2, probs) and torch.equal(v2, value)
+
+
 def test_rejects_non_state_input():
     from alphazero_amd.model import AlphaZeroNet, HipInference
     from alphazero_amd._lib import AzError
@@ -200,4 +271,4 @@ def test_rejects_non_state_input():
     with pytest.raises(AzError):
         inf.forward_planes(torch.randn(4, 3, 8, 8).cuda())
     with pytest.raises(AzError):
-        HipInference(AlphaZeroNet(num_blocks=1, num_filters=32))
+        HipInference(AlphaZeroNet(num_blocks=1, num_filters=48))     # not a multiple of 32

@@ -209,14 +209,20 @@ def test_full_size_fused_search_equals_the_oracle_on_sampled_games():
     small.close()
 
 
-def test_fused_search_with_the_real_network_equals_the_oracle(small_model):
+@pytest.mark.parametrize("net", ["2x128", "2x32", "1x64 se 4"])
+def test_fused_search_with_the_real_network_equals_the_oracle(small_model, net):
     """The whole fused path (HIP network inside the library, 800 simulations, injected root
     noise, tree reuse over two plies) against the CPU oracle driven with the same network's
-    outputs: identical visit counts, value sums and priors for every root."""
+    outputs: identical visit counts, value sums and priors for every root.  Also with the
+    reference's test network (2 x 32, tests/test_mcts.py:54) and another width, which run the
+    any-width kernels with the device row assignment."""
     from alphazero_amd.engine import Engine
-    from alphazero_amd.model import HipInference
+    from alphazero_amd.model import AlphaZeroNet, HipInference
     nG, S = 8, 800
-    inf = HipInference(small_model, max_batch=16)
+    torch.manual_seed(8)
+    model = {"2x128": small_model, "2x32": AlphaZeroNet(num_blocks=2, num_filters=32).eval(),
+             "1x64 se 4": AlphaZeroNet(num_blocks=1, num_filters=64, se_ratio=4).eval()}[net]
+    inf = HipInference(model, max_batch=16)
     w, b, t, win = orc.random_positions(900, seed=21)
     idx = [i for i in range(900) if win[i] == 0 and orc.legal_actions(orc.make_pos(w[i], b[i], t[i])).size][:: 900 // nG][:nG]
     dev = Engine(nG, pool_nodes_per_game=1 << 16)

@@ -15,9 +15,11 @@ if __name__ == "__main__":
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--blocks", type=int, default=20)
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--filters", type=int, default=128, help="other than 128 (or --se-ratio other than 8): the any-width kernel")
+    ap.add_argument("--se-ratio", type=int, default=8)
     a = ap.parse_args()
     torch.manual_seed(0)
-    model = AlphaZeroNet(num_blocks=a.blocks, num_filters=128).eval()
+    model = AlphaZeroNet(num_blocks=a.blocks, num_filters=a.filters, se_ratio=a.se_ratio).eval()
     inf = HipInference(model, max_batch=a.batch)
     g = torch.Generator().manual_seed(1)
     mine = torch.randint(0, 2**62, (a.batch,), generator=g, dtype=torch.int64).cuda()
@@ -32,7 +34,11 @@ if __name__ == "__main__":
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.iters
-    tf = FLOP_PER_POS * a.batch / (ms * 1e-3) / 1e12 * (a.blocks * 2 + 1 + 0.05) / 41.05
+    conv = 2 * 64 * 9 * a.filters * a.filters          # FLOP of one 3x3 conv over a position
+    flop = conv * (2 * a.blocks + 1) + 2 * 64 * 27 * a.filters + 2 * 64 * a.filters * 32 + 2 * 64 * a.filters * 192 + 2 * 2048 * 128
+    if a.filters == 128 and a.se_ratio == 8:
+        flop = FLOP_PER_POS * (a.blocks * 2 + 1 + 0.05) / 41.05
+    tf = flop * a.batch / (ms * 1e-3) / 1e12
     if os.environ.get("AZ_TOWER_STAMPS"):
         import ctypes as C
         import numpy as np
@@ -53,4 +59,4 @@ if __name__ == "__main__":
               f"workgroup duration min/mean/max {buf[:,3].min()/100:.1f}/{ticks/100:.1f}/{buf[:,3].max()/100:.1f} us, "
               f"first start to last end {(int(buf[:,9].max()) - int(buf[:,8].min()))/100:.1f} us, start skew {(int(buf[:,8].max()) - int(buf[:,8].min()))/100:.1f} us; "
               f"stamp counter rate {tot / (ticks / 100e6) / 1e9:.3f} GHz over {ticks / 100:.1f} us")
-    print(f"batch {a.batch} blocks {a.blocks}: {ms:.3f} ms/forward, {a.batch / ms * 1e3:.0f} pos/s, ~{tf:.1f} TFLOP/s")
+    print(f"batch {a.batch} blocks {a.blocks} filters {a.filters} se_ratio {a.se_ratio}: {ms:.3f} ms/forward, {a.batch / ms * 1e3:.0f} pos/s, ~{tf:.1f} TFLOP/s")
