@@ -8,16 +8,18 @@
 // activations of the position sit in two LDS images [64 px][C] bf16 (pixel pitch 2C + 16 bytes);
 // a conv reads one and writes the other, the block's output goes back over the block's input (the
 // residual, which each lane reads at exactly the addresses it then writes).  Weights are read as
-// MFMA fragments straight from global memory (L2): with one position per workgroup nothing is
-// reused inside it, which is why the 128-wide kernels (four positions per workgroup, weights
+// MFMA fragments straight from global memory (L2), a few k-steps ahead of the MFMAs that use them
+// (a register ring): with one position per workgroup nothing is reused inside it, which is why the 128-wide kernels (four positions per workgroup, weights
 // staged through LDS) are the ones to use at that width.  Same arithmetic as those kernels:
 // bf16 operands, float32 accumulation started from the folded-BN bias, float32 squeeze-excitation.
 #include "tower_common.h"
 
 namespace az {
 
-constexpr int ANY_MAX_CH = 256;
-constexpr int ANY_MAX_PITCH = 2 * ANY_MAX_CH + 16;
+// fragments of a conv's weight stream kept in flight ahead of the MFMAs: D k-steps of NT fragments
+// (at most 36 fragments = 144 registers)
+template <int NT>
+struct AnyDepth { static constexpr int D = NT <= 2 ? 9 : (NT <= 4 ? 6 : (NT <= 6 ? 5 : (NT <= 8 ? 4 : (NT <= 12 ? 3 : 2)))); };
 
 __device__ __forceinline__ float row16_sum(float v) {
     v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x128, 0xF, 0xF, true));  // row_ror:8
@@ -27,17 +29,20 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// NT = C / 16 channel tiles (C = 32, 64, ..., 256)
+template <int NT>
 __global__ __launch_bounds__(256) void k_tower_any(TowerParams p) {
-    __shared__ __attribute__((aligned(16))) char act[2 * 64 * ANY_MAX_PITCH];
-    __shared__ __attribute__((aligned(16))) char zero_row[ANY_MAX_PITCH];
-    __shared__ float part[4][ANY_MAX_CH];
-    __shared__ float mean[ANY_MAX_CH];
-    __shared__ float hid[ANY_MAX_CH];
-    __shared__ __attribute__((aligned(16))) float gate[2 * ANY_MAX_CH];   // gate[0, C), shift[C, 2C)
+    constexpr int C = NT * 16, KS = NT / 2, P = 2 * C + 16, T = 9 * KS, D = AnyDepth<NT>::D;
+    __shared__ __attribute__((aligned(16))) char act[2 * 64 * P];
+    __shared__ __attribute__((aligned(16))) char zero_row[P];
+    __shared__ float part[4][C];
+    __shared__ float mean[C];
+    __shared__ float hid[C];
+    __shared__ __attribute__((aligned(16))) float gate[2 * C];   // gate[0, C), shift[C, 2C)
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int c = lane & 15, q = lane >> 4;   // pixel of the wave's tile / k quarter (operands), channel quad (accumulators)
-    const int C = p.ch, NT = C >> 4, KS = C >> 5, H = p.se_hid, P = 2 * C + 16;
+    const int H = p.se_hid;
     const int pos = blockIdx.x;
     int src = pos;
     if (p.need) {
@@ -45,46 +50,53 @@ __global__ __launch_bounds__(256) void k_tower_any(TowerParams p) {
         src = assign_rows<256, 1>(p, tid, 0, has_rows);
         if (!has_rows) return;
     }
-    for (int i = tid; i < ANY_MAX_PITCH / 4; i += 256) reinterpret_cast<uint32_t*>(zero_row)[i] = 0;
+    for (int i = tid; i < P / 4; i += 256) reinterpret_cast<uint32_t*>(zero_row)[i] = 0;
 
     const int px = wave * 16 + c, py = px >> 3, pxx = px & 7;
     char* regA = act;
     char* regB = act + 64 * P;
-    f32x4 acc[16];
+    f32x4 acc[NT];
 
     // acc -> ReLU -> bf16 -> this lane's pixel in `out` (8 bytes per channel tile)
     auto store_relu = [&](char* out) {
 #pragma unroll
-        for (int nt = 0; nt < 16; ++nt)
-            if (nt < NT) {
-                const uint2 o = make_uint2(relu_bf16x2(pack_bf16x2(acc[nt][0], acc[nt][1])),
-                                           relu_bf16x2(pack_bf16x2(acc[nt][2], acc[nt][3])));
-                *reinterpret_cast<uint2*>(out + px * P + (nt * 16 + q * 4) * 2) = o;
-            }
+        for (int nt = 0; nt < NT; ++nt) {
+            const uint2 o = make_uint2(relu_bf16x2(pack_bf16x2(acc[nt][0], acc[nt][1])),
+                                       relu_bf16x2(pack_bf16x2(acc[nt][2], acc[nt][3])));
+            *reinterpret_cast<uint2*>(out + px * P + (nt * 16 + q * 4) * 2) = o;
+        }
     };
-    // 3x3 conv number ci over the image `in`: acc = bias + sum over taps and k-steps
+    // 3x3 conv number ci over the image `in`: acc = bias + sum over taps and k-steps.  The conv's
+    // weights are one contiguous stream of T x NT fragments; D k-steps of them are in flight.
     auto conv3x3 = [&](int ci, const char* in) {
         const float* bias = p.conv_b + (size_t)ci * C + q * 4;
 #pragma unroll
-        for (int nt = 0; nt < 16; ++nt)
-            if (nt < NT) acc[nt] = *reinterpret_cast<const f32x4*>(bias + nt * 16);
-        const uint8_t* wconv = p.conv_w + (size_t)ci * 9 * KS * NT * 1024 + lane * 16;
-        for (int tap = 0; tap < 9; ++tap) {
-            const int y = py + tap / 3 - 1, x = pxx + tap % 3 - 1;
-            const bool ok = (y >= 0) && (y < 8) && (x >= 0) && (x < 8);
-            const char* xrow = (ok ? in + (y * 8 + x) * P : zero_row) + q * 16;
-            const uint8_t* wtap = wconv + (size_t)tap * KS * NT * 1024;
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 xb = *reinterpret_cast<const bf16x8*>(xrow + ks * 64);
-                const uint8_t* wk = wtap + (size_t)ks * NT * 1024;
-                bf16x8 w[16];
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = *reinterpret_cast<const f32x4*>(bias + nt * 16);
+        const uint8_t* wconv = p.conv_w + (size_t)ci * T * NT * 1024 + lane * 16;
+        bf16x8 ring[D][NT];
 #pragma unroll
-                for (int nt = 0; nt < 16; ++nt)
-                    if (nt < NT) w[nt] = *reinterpret_cast<const bf16x8*>(wk + nt * 1024);
+        for (int d = 0; d < D && d < T; ++d)
 #pragma unroll
-                for (int nt = 0; nt < 16; ++nt)
-                    if (nt < NT) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nt], xb, acc[nt], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt) ring[d][nt] = *reinterpret_cast<const bf16x8*>(wconv + (size_t)(d * NT + nt) * 1024);
+        const char* xrow = nullptr;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int tap = t / KS, ks = t % KS;
+            if (ks == 0) {
+                const int y = py + tap / 3 - 1, x = pxx + tap % 3 - 1;
+                const bool ok = (y >= 0) && (y < 8) && (x >= 0) && (x < 8);
+                xrow = (ok ? in + (y * 8 + x) * P : zero_row) + q * 16;
             }
+            const bf16x8 xb = *reinterpret_cast<const bf16x8*>(xrow + ks * 64);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[t % D][nt], xb, acc[nt], 0, 0, 0);
+            if (t + D < T) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    ring[t % D][nt] = *reinterpret_cast<const bf16x8*>(wconv + (size_t)((t + D) * NT + nt) * 1024);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // or the scheduler sinks every load to just before its use
         }
     };
 
@@ -103,12 +115,11 @@ __global__ __launch_bounds__(256) void k_tower_any(TowerParams p) {
             xb[j] = (__bf16)((ok && ((plane >> sq) & 1ull)) ? 1.0f : 0.0f);
         }
 #pragma unroll
-        for (int nt = 0; nt < 16; ++nt)
-            if (nt < NT) {
-                const bf16x8 w = *reinterpret_cast<const bf16x8*>(p.stem_w + (nt * 64 + lane) * 16);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(p.stem_b + nt * 16 + q * 4);
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, xb, b, 0, 0, 0);
-            }
+        for (int nt = 0; nt < NT; ++nt) {
+            const bf16x8 w = *reinterpret_cast<const bf16x8*>(p.stem_w + (nt * 64 + lane) * 16);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(p.stem_b + nt * 16 + q * 4);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, xb, b, 0, 0, 0);
+        }
         store_relu(regA);
     }
     __syncthreads();   // image A and the zero row are complete
@@ -121,13 +132,11 @@ __global__ __launch_bounds__(256) void k_tower_any(TowerParams p) {
         conv3x3(2 * blk + 1, regB);
         // squeeze: channel sums over this wave's 16 pixels, then over the four waves
 #pragma unroll
-        for (int nt = 0; nt < 16; ++nt)
-            if (nt < NT) {
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float s = row16_sum(acc[nt][i]);
-                    if (c == 0) part[wave][nt * 16 + q * 4 + i] = s;
-                }
+            for (int i = 0; i < 4; ++i) {
+                const float s = row16_sum(acc[nt][i]);
+                if (c == 0) part[wave][nt * 16 + q * 4 + i] = s;
             }
         __syncthreads();
         if (tid < C) mean[tid] = ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) * (1.0f / 64.0f);
@@ -152,19 +161,18 @@ __global__ __launch_bounds__(256) void k_tower_any(TowerParams p) {
         __syncthreads();
         // out = relu(z * gate + shift + residual), over the block's input
 #pragma unroll
-        for (int nt = 0; nt < 16; ++nt)
-            if (nt < NT) {
-                const int ch0 = nt * 16 + q * 4;
-                uint2* cell = reinterpret_cast<uint2*>(regA + px * P + ch0 * 2);
-                const uint2 r = *cell;
-                const f32x4 g = *reinterpret_cast<const f32x4*>(gate + ch0);
-                const f32x4 sh = *reinterpret_cast<const f32x4*>(gate + C + ch0);
-                const float o0 = acc[nt][0] * g[0] + sh[0] + bf16_lo(r.x);
-                const float o1 = acc[nt][1] * g[1] + sh[1] + bf16_hi(r.x);
-                const float o2 = acc[nt][2] * g[2] + sh[2] + bf16_lo(r.y);
-                const float o3 = acc[nt][3] * g[3] + sh[3] + bf16_hi(r.y);
-                *cell = make_uint2(relu_bf16x2(pack_bf16x2(o0, o1)), relu_bf16x2(pack_bf16x2(o2, o3)));
-            }
+        for (int nt = 0; nt < NT; ++nt) {
+            const int ch0 = nt * 16 + q * 4;
+            uint2* cell = reinterpret_cast<uint2*>(regA + px * P + ch0 * 2);
+            const uint2 r = *cell;
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gate + ch0);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(gate + C + ch0);
+            const float o0 = acc[nt][0] * g[0] + sh[0] + bf16_lo(r.x);
+            const float o1 = acc[nt][1] * g[1] + sh[1] + bf16_hi(r.x);
+            const float o2 = acc[nt][2] * g[2] + sh[2] + bf16_lo(r.y);
+            const float o3 = acc[nt][3] * g[3] + sh[3] + bf16_hi(r.y);
+            *cell = make_uint2(relu_bf16x2(pack_bf16x2(o0, o1)), relu_bf16x2(pack_bf16x2(o2, o3)));
+        }
         __syncthreads();
     }
 
@@ -173,6 +181,7 @@ __global__ __launch_bounds__(256) void k_tower_any(TowerParams p) {
         f32x4 va[2];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) va[nt] = *reinterpret_cast<const f32x4*>(p.value_b + nt * 16 + q * 4);
+#pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const bf16x8 xb = *reinterpret_cast<const bf16x8*>(regA + px * P + ks * 64 + q * 16);
 #pragma unroll
@@ -204,7 +213,16 @@ __global__ __launch_bounds__(256) void k_tower_any(TowerParams p) {
 }
 
 void launch_tower_any(const TowerParams& tp, int B, hipStream_t s) {
-    hipLaunchKernelGGL(k_tower_any, dim3(B), dim3(256), 0, s, tp);
+    switch (tp.ch / 32) {   // az_net_create admits exactly these widths
+        case 1: hipLaunchKernelGGL(k_tower_any<2>, dim3(B), dim3(256), 0, s, tp); break;
+        case 2: hipLaunchKernelGGL(k_tower_any<4>, dim3(B), dim3(256), 0, s, tp); break;
+        case 3: hipLaunchKernelGGL(k_tower_any<6>, dim3(B), dim3(256), 0, s, tp); break;
+        case 4: hipLaunchKernelGGL(k_tower_any<8>, dim3(B), dim3(256), 0, s, tp); break;
+        case 5: hipLaunchKernelGGL(k_tower_any<10>, dim3(B), dim3(256), 0, s, tp); break;
+        case 6: hipLaunchKernelGGL(k_tower_any<12>, dim3(B), dim3(256), 0, s, tp); break;
+        case 7: hipLaunchKernelGGL(k_tower_any<14>, dim3(B), dim3(256), 0, s, tp); break;
+        default: hipLaunchKernelGGL(k_tower_any<16>, dim3(B), dim3(256), 0, s, tp); break;
+    }
 }
 
 }  // namespace az
