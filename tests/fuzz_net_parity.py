@@ -2,8 +2,9 @@
 
 Per round: a block count, fresh random weights with non-trivial BatchNorm statistics (scaled
 so that some rounds have sharply peaked policies), a batch size that lands anywhere in or
-between the size classes of the tower kernel, one of its forms, positions from seeded random
-play.  Checks: max-abs error of policy probabilities and value within the 2e-2 tolerance,
+between the size classes of the tower kernel, one of its forms (in a quarter of the rounds
+another width and squeeze-excitation ratio instead: the any-width kernels), positions from
+seeded random play.  Checks: max-abs error of policy probabilities and value within the 2e-2 tolerance,
 probabilities summing to one, every row of the batch equal bit for bit to the same position
 evaluated alone and at another row of another batch (same form), and the batch reproducible.
 
@@ -27,10 +28,10 @@ from oracle import oracle as orc  # noqa: E402
 TOL = 2e-2
 
 
-def _random_model(rs, blocks):
+def _random_model(rs, blocks, filters=128, se_ratio=8):
     from alphazero_amd.model import AlphaZeroNet
     torch.manual_seed(int(rs.randint(1 << 30)))
-    model = AlphaZeroNet(num_blocks=blocks, num_filters=128)
+    model = AlphaZeroNet(num_blocks=blocks, num_filters=filters, se_ratio=se_ratio)
     g = torch.Generator().manual_seed(int(rs.randint(1 << 30)))
     gain = float(rs.choice([0.7, 1.0, 1.3]))
     for mod in model.modules():
@@ -53,7 +54,13 @@ def one_round(seed, max_batch=1100, verbose=False):
     blocks = int(rs.choice([1, 2, 3, 5, 8]))
     B = int(rs.choice([1, 2, 3, 4, 5, 15, 16, 17, 255, 256, 257, 511, 512, 513, int(rs.randint(1, max_batch))]))
     form = int(rs.choice([0, 1, 2, 4, 8, 16]))
-    model = _random_model(rs, blocks)
+    filters, se_ratio = 128, 8
+    if rs.randint(4) == 0:   # another width: the any-width kernels (one form; row independence is checked all the same)
+        filters = int(rs.choice([32, 64, 96, 128, 160, 192, 224, 256]))
+        se_ratio = int(rs.choice([r for r in (1, 2, 4, 8, 16, 32) if (filters, r) != (128, 8)]))
+        form = -1
+        B = min(B, 300)
+    model = _random_model(rs, blocks, filters, se_ratio)
     w, b, t, _ = orc.random_positions(B, seed)
     _, _, planes, _ = orc.movegen_batch(w, b, t, want_mask=False)
     x = torch.from_numpy(planes)
@@ -64,7 +71,7 @@ def one_round(seed, max_batch=1100, verbose=False):
     value_ref = wlp[:, 0] - wlp[:, 1]
     inf = HipInference(model, max_batch=max(B, 16))
     try:
-        inf.set_tower_form(form)
+        inf.set_tower_form(max(form, 0))
         xd = x.cuda()
         probs, value, _, _ = inf.forward_planes(xd)
         probs, value = probs.clone(), value.clone()
@@ -73,7 +80,7 @@ def one_round(seed, max_batch=1100, verbose=False):
         pn, vn = probs.cpu().numpy(), value.cpu().numpy()
         err_p, err_v = float(np.abs(pn - probs_ref).max()), float(np.abs(vn - value_ref).max())
         assert np.allclose(pn.sum(1), 1.0, atol=1e-4), f"seed {seed}: probabilities do not sum to one"
-        assert err_p <= TOL and err_v <= TOL, f"seed {seed}: blocks {blocks} B {B} form {form}: {err_p:.3e} {err_v:.3e}"
+        assert err_p <= TOL and err_v <= TOL, f"seed {seed}: blocks {blocks} x {filters} / {se_ratio} B {B} form {form}: {err_p:.3e} {err_v:.3e}"
         if form:   # a position's result must not depend on its row or on its neighbours
             for i in {0, B - 1, int(rs.randint(B))}:
                 p1, v1, _, _ = inf.forward_planes(xd[i:i + 1].contiguous())
@@ -87,7 +94,7 @@ def one_round(seed, max_batch=1100, verbose=False):
         inf.close()
     top1 = float((pn.argmax(1) == probs_ref.argmax(1)).mean())
     if verbose:
-        print(f"seed {seed}: blocks {blocks} B {B} form {form}: max|dprobs| {err_p:.2e} max|dvalue| {err_v:.2e} "
+        print(f"seed {seed}: blocks {blocks} filters {filters} se_ratio {se_ratio} B {B} form {form}: max|dprobs| {err_p:.2e} max|dvalue| {err_v:.2e} "
               f"top1 {top1:.4f} peak prob {probs_ref.max():.2f}", flush=True)
     return err_p, err_v, top1, B
 

@@ -1,13 +1,16 @@
 #!/bin/bash
-# The three differential fuzzers on the current kernels (GPU box): bash tools/fuzz_all.sh <out file under gpurun_out/>
+# The three differential fuzzers on the current kernels (GPU box; each writes its progress to a log under gpurun_out/):
+#   bash tools/fuzz_all.sh <out file under gpurun_out/> [tree rounds] [fused rounds] [net rounds] [seed offset]
 OUT=gpurun_out/${1:-fuzz_parity.txt}
+TR=${2:-3000}; FR=${3:-3000}; NR=${4:-1000}; SO=${5:-0}
+S1=$((21001 + SO)); S2=$((31001 + SO)); S3=$((41001 + SO))
 mkdir -p gpurun_out
 {
-echo "## python3 tests/fuzz_tree_parity.py --rounds 3000 --seed 21001   (device engine vs the C oracle)"
-timeout -k 10 500 python3 -u tests/fuzz_tree_parity.py --rounds 3000 --seed 21001 2>&1 | tail -1
-echo "## python3 tests/fuzz_fused_parity.py --rounds 3000 --seed 31001   (fused search, device row assignment, every tower form incl. 16, vs the step API)"
-timeout -k 10 400 python3 -u tests/fuzz_fused_parity.py --rounds 3000 --seed 31001 2>&1 | tail -1
-echo "## python3 tests/fuzz_net_parity.py --rounds 1000 --seed 41001   (HIP forward, every tower form incl. 16, vs float32 torch)"
-timeout -k 10 400 python3 -u tests/fuzz_net_parity.py --rounds 1000 --seed 41001 2>&1 | tail -1
+echo "## python3 tests/fuzz_tree_parity.py --rounds $TR --seed $S1   (device engine vs the C oracle)"
+timeout -k 10 1000 python3 -u tests/fuzz_tree_parity.py --rounds $TR --seed $S1 > gpurun_out/fuzz_tree.log 2>&1; tail -1 gpurun_out/fuzz_tree.log
+echo "## python3 tests/fuzz_fused_parity.py --rounds $FR --seed $S2   (fused search, device row assignment, every tower form incl. 16, vs the step API)"
+timeout -k 10 600 python3 -u tests/fuzz_fused_parity.py --rounds $FR --seed $S2 > gpurun_out/fuzz_fused.log 2>&1; tail -1 gpurun_out/fuzz_fused.log
+echo "## python3 tests/fuzz_net_parity.py --rounds $NR --seed $S3   (HIP forward, every tower form incl. 16 and, in a quarter of the rounds, another width, vs float32 torch)"
+timeout -k 10 600 python3 -u tests/fuzz_net_parity.py --rounds $NR --seed $S3 > gpurun_out/fuzz_net.log 2>&1; tail -1 gpurun_out/fuzz_net.log
 } > $OUT 2>&1
 cat $OUT
