@@ -6,8 +6,8 @@
 // What differs from k_tower:
 //   * a wave's tile is 8 channel tiles x 4 pixel tiles of 16 x 16, a k-step is 32 input channels
 //     (4 k-steps per tap, 32 MFMAs and 12 fragment reads each);
-//   * an accumulator lane holds 4 channels of ONE pixel, so the squeeze is a reduce-scatter of 32
-//     values over the 16 lanes of a DPP row (30 exchanges against 64), the gate / shift / bias
+//   * an accumulator lane holds 4 channels of ONE pixel, so the squeeze is an all-reduce of 32
+//     values over the 16 lanes of a DPP row (four v_add_f32 row_ror each), the gate / shift / bias
 //     vectors a lane needs are 32 channels (8 reads of 16 B) and the epilogue stores 16 bytes
 //     per instruction;
 //   * activations in LDS: 256 bytes per pixel with no padding.  The 16-byte chunk of channels
@@ -21,7 +21,9 @@
 //   * output channels are numbered so that the two channel tiles 2t, 2t + 1 hold, per lane, the
 //     8 consecutive channels of one chunk: tile nt, row 4 q + i  <->  channel
 //     (nt >> 1) * 32 + q * 8 + (nt & 1) * 4 + i.  The weight images carry that order
-//     (pack_conv3x3_16 in net.hip).
+//     (pack_conv3x3_16 in net.hip);
+//   * built with the accumulators in AGPRs (the compiler's default; see build.sh), and the block
+//     loop runs the two convs of a block per pass, so a conv's parity is a literal.
 #include "tower_common.h"
 
 namespace az {
@@ -135,21 +137,18 @@ __global__ __launch_bounds__(256, 1) void k_tower16(TowerParams p) {
         const uint32_t dst = lds_base + L16_W + (T & 1) * TAP_BYTES + wave_u * 8192;
         glds16x8(src + 4096, __builtin_amdgcn_readfirstlane(dst + 4096));
     };
-    auto prefetch_half = [&](int T, int half) {
-        const uint8_t* src = p.conv_w + (size_t)T * TAP_BYTES + wave_u * 8192 + lane * 16;
-        const uint32_t dst = lds_base + L16_W + (T & 1) * TAP_BYTES + wave_u * 8192;
-        if (half == 0) glds16x4_lo(src + 4096, __builtin_amdgcn_readfirstlane(dst + 4096));
-        else glds16x4_hi(src + 4096, __builtin_amdgcn_readfirstlane(dst + 4096));
-    };
+    // (no branches round these copies: they sit in the tap loop, which is one basic block without them.
+    // Waves 2, 3 copy the halves of the bias row that waves 0, 1 copy; a piece index past the image
+    // copies the last piece again.)
     auto prefetch_bias = [&](int cv) {
-        if (wave_u < 2)
-            glds4(reinterpret_cast<const uint8_t*>(p.conv_b + (size_t)cv * CH) + wave_u * 256 + lane * 4,
-                  __builtin_amdgcn_readfirstlane(lds_base + L16_BIAS + (cv & 1) * 512 + wave_u * 256));
+        const int half = wave_u & 1;
+        glds4(reinterpret_cast<const uint8_t*>(p.conv_b + (size_t)cv * CH) + half * 256 + lane * 4,
+              __builtin_amdgcn_readfirstlane(lds_base + L16_BIAS + (cv & 1) * 512 + half * 256));
     };
     auto prefetch_se = [&](int blk, int piece) {
-        if (piece < SE_PIECES)
-            glds16(p.se_img + (size_t)blk * SE_BYTES + piece * 1024 + lane * 16,
-                   __builtin_amdgcn_readfirstlane(lds_base + L16_SE + piece * 1024));
+        const int pc = piece < SE_PIECES ? piece : SE_PIECES - 1;
+        glds16(p.se_img + (size_t)blk * SE_BYTES + pc * 1024 + lane * 16,
+               __builtin_amdgcn_readfirstlane(lds_base + L16_SE + pc * 1024));
     };
     prefetch(0);
     prefetch_bias(0);
@@ -220,10 +219,12 @@ __global__ __launch_bounds__(256, 1) void k_tower16(TowerParams p) {
 
     unsigned long long t_loop = 0, t_ep1 = 0, t_ep2 = 0, t_sq = 0, t_f1 = 0, t_f2 = 0, t_fin = 0;
     const unsigned long long rt0 = p.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    for (int conv = 0; conv < nconv; ++conv) {
-        const unsigned long long ts0 = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+    // One conv's bias fill and tap loop.  `par` is the parity of conv as a literal at every call (the
+    // block loop below runs two convs per pass), so the weight buffer of a tap and the bias row are
+    // immediates, and the residual / address registers of the two epilogue kinds never meet in a phi.
+    uint32_t oz;
+    auto run_conv = [&](const int conv, const int par) __attribute__((always_inline)) {
         // opaque per-pass constants (see load_frags16) and an opaque zero for the epilogue addresses
-        uint32_t oz;
         asm volatile("v_mov_b32 %0, 0" : "=v"(oz));
         asm volatile("v_mov_b32 %0, 16" : "=v"(k16[1]));
         asm volatile("v_mov_b32 %0, 32" : "=v"(k16[2]));
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(256, 1) void k_tower16(TowerParams p) {
         k16[0] = 0;
         // the accumulators start from the folded-BN bias of this conv (in LDS since the previous conv)
         {
-            const float* b0 = reinterpret_cast<const float*>(lds + L16_BIAS + (conv & 1) * 512) + q * 8;
+            const float* b0 = reinterpret_cast<const float*>(lds + L16_BIAS + par * 512) + q * 8;
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) {
                 const f32x4 b = *reinterpret_cast<const f32x4*>(b0 + (nt >> 1) * 32 + (nt & 1) * 4);
@@ -244,13 +245,14 @@ __global__ __launch_bounds__(256, 1) void k_tower16(TowerParams p) {
         // fragments are in registers by then), so the first fragments of the next tap are read
         // behind it, under that k-step's MFMAs.
         Frags16 f0, f1;
-        load_frags16(f0, lds, aaddr[0], L16_W + ((conv * 9) & 1) * TAP_BYTES + lane * 16, 0, k16);
+        load_frags16(f0, lds, aaddr[0], L16_W + par * TAP_BYTES + lane * 16, 0, k16);
         if (AZ_T16_DIAG >= 4) f1 = f0;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int T = conv * 9 + tap;
-            const uint32_t wb = L16_W + (T & 1) * TAP_BYTES + lane * 16;
-            const uint32_t wb_next = L16_W + ((T + 1) & 1) * TAP_BYTES + lane * 16;
+            const int tpar = par ^ (tap & 1);   // T & 1
+            const uint32_t wb = L16_W + tpar * TAP_BYTES + lane * 16;
+            const uint32_t wb_next = L16_W + (tpar ^ 1) * TAP_BYTES + lane * 16;
             // k-step 0: also carries the copy of the next tap (its buffer was released by the barrier
             // inside the previous tap) and the bias / SE pieces, between groups of MFMAs
             // Eight groups of four MFMAs; behind each of them one 1 KB piece of the next tap's copy, so
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(256, 1) void k_tower16(TowerParams p) {
             {
                 const int Tn = (T + 1 < total_taps) ? T + 1 : total_taps - 1;
                 const uint8_t* src = p.conv_w + (size_t)Tn * TAP_BYTES + wave_u * 8192 + lane * 16 + 4096;
-                const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + L16_W + ((T + 1) & 1) * TAP_BYTES + wave_u * 8192 + 4096);
+                const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + L16_W + (tpar ^ 1) * TAP_BYTES + wave_u * 8192 + 4096);
                 auto group = [](int reads) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                     if (reads > 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(256, 1) void k_tower16(TowerParams p) {
                 if (tap == 0) prefetch_bias(conv + 1);   // the bias array has a spare row past the last conv
                 mma16<7, 8>(acc, f0); group(0);
                 glds16_piece<3072>(src, dst);
-                if ((conv & 1) && tap < 7 && conv < nconv - 1) prefetch_se(conv >> 1, tap * 4 + wave_u);
+                if (par && tap < 7) prefetch_se(conv >> 1, tap * 4 + wave_u);   // an odd conv is the second of a block
             }
             // k-step 1
             load_frags16(f0, lds, aaddr[tap], wb, 2, k16);
@@ -316,37 +318,38 @@ __global__ __launch_bounds__(256, 1) void k_tower16(TowerParams p) {
             mma16<0, 8>(acc, f1);
             interleave16();
         }
-        const unsigned long long ts1 = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-        // this lane's store addresses: pixel c of tile 0, chunk t of quarter q
-        uint32_t wa[4];
+    };
+    // this lane's store addresses after a conv: pixel c of tile 0, chunk t of quarter q
+    auto store_addresses = [&](uint32_t (&wa)[4]) __attribute__((always_inline)) {
+        const uint32_t w0 = oz + (uint32_t)(L16_ACT + wave * A16_REGION + c * A16_ROW + ((qpos ^ (c & 7)) * 16));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wa[t] = w0 ^ k16[t];
+    };
+    auto stamp = [&]() __attribute__((always_inline)) { return p.stamps ? __builtin_amdgcn_s_memtime() : 0ull; };
+
+    for (int blk = 0; blk < p.blocks; ++blk) {
+        // ---- conv1 of the block: ReLU -> LDS
         {
-            const uint32_t w0 = oz + (uint32_t)(L16_ACT + wave * A16_REGION + c * A16_ROW + ((qpos ^ (c & 7)) * 16));
-#pragma unroll
-            for (int t = 0; t < 4; ++t) wa[t] = w0 ^ k16[t];
+            const unsigned long long ts0 = stamp();
+            run_conv(2 * blk, 0);
+            const unsigned long long ts1 = stamp();
+            uint32_t wa[4];
+            store_addresses(wa);
+            store_act16<true, false, false>(lds, wa, acc, nullptr, resid, q);
+            if (p.stamps) { const unsigned long long ts2 = stamp(); t_loop += ts1 - ts0; t_ep1 += ts2 - ts1; }
         }
+        // ---- conv2 of the block: SE, + residual, ReLU -> LDS and registers
+        const int conv = 2 * blk + 1;
+        const unsigned long long ts0 = stamp();
+        run_conv(conv, 1);
+        const unsigned long long ts1 = stamp();
+        uint32_t wa[4];
+        store_addresses(wa);
         char* region = lds + oz + L16_ACT + wave * A16_REGION;
-        if (conv == nconv - 1) {
-            // ---- policy conv: ReLU -> LDS -> p_act (coalesced 16 B per lane)
-            store_act16<true, false, false>(lds, wa, acc, nullptr, resid, q);
-            if (live) {
-                char* out = reinterpret_cast<char*>(p.p_act) + (size_t)(pos >> 4) * (POLICY_K / 32) * 1024 + (pos & 15) * 64;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int idx = i * 64 + lane;  // 16-byte granule: pixel idx / 16, channels [8 (idx % 16), +8)
-                    const int px = idx >> 4, lc = idx & 15;
-                    const int chunk = (((lc & 1) * 8 + ((lc >> 1) & 1) * 4 + (lc >> 2)) ^ (px & 7));
-                    const uint4 v = *reinterpret_cast<const uint4*>(region + px * A16_ROW + chunk * 16);
-                    *reinterpret_cast<uint4*>(out + (idx >> 2) * 1024 + (idx & 3) * 16) = v;
-                }
-            }
-        } else if ((conv & 1) == 0) {
-            // ---- conv1 of a block: ReLU -> LDS
-            store_act16<true, false, false>(lds, wa, acc, nullptr, resid, q);
-        } else {
-            // ---- conv2 of a block: SE, + residual, ReLU -> LDS and registers
+        {
             float* scratch = reinterpret_cast<float*>(region);  // the region is free now
             const float* se = reinterpret_cast<const float*>(lds + oz + L16_SE);
-            if (p.dbg & 1) {
+            if (p.dbg & 1) {   // diagnostic ablation: no squeeze-excitation
                 store_act16<true, true, false>(lds, wa, acc, nullptr, resid, q);
                 continue;
             }
@@ -495,11 +498,29 @@ __global__ __launch_bounds__(256, 1) void k_tower16(TowerParams p) {
                 }
             }
         }
-        if (p.stamps) {
-            const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
-            t_loop += ts1 - ts0;
-            if (conv & 1) t_ep2 += ts2 - ts1; else t_ep1 += ts2 - ts1;
+        if (p.stamps) { const unsigned long long ts2 = stamp(); t_loop += ts1 - ts0; t_ep2 += ts2 - ts1; }
+    }
+    // ---- policy conv: ReLU -> LDS -> p_act (coalesced 16 B per lane)
+    {
+        const unsigned long long ts0 = stamp();
+        run_conv(nconv - 1, 0);
+        const unsigned long long ts1 = stamp();
+        uint32_t wa[4];
+        store_addresses(wa);
+        char* region = lds + oz + L16_ACT + wave * A16_REGION;
+        store_act16<true, false, false>(lds, wa, acc, nullptr, resid, q);
+        if (live) {
+            char* out = reinterpret_cast<char*>(p.p_act) + (size_t)(pos >> 4) * (POLICY_K / 32) * 1024 + (pos & 15) * 64;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int idx = i * 64 + lane;  // 16-byte granule: pixel idx / 16, channels [8 (idx % 16), +8)
+                const int px = idx >> 4, lc = idx & 15;
+                const int chunk = (((lc & 1) * 8 + ((lc >> 1) & 1) * 4 + (lc >> 2)) ^ (px & 7));
+                const uint4 v = *reinterpret_cast<const uint4*>(region + px * A16_ROW + chunk * 16);
+                *reinterpret_cast<uint4*>(out + (idx >> 2) * 1024 + (idx & 3) * 16) = v;
+            }
         }
+        if (p.stamps) { const unsigned long long ts2 = stamp(); t_loop += ts1 - ts0; t_ep1 += ts2 - ts1; }
     }
     if (p.stamps && tid == 0) {
         unsigned long long* o = p.stamps + blockIdx.x * 10;
