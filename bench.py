@@ -244,6 +244,15 @@ def secondary_block(blocks):
     return out
 
 
+def tower_kernel_name(rows):
+    """The tower kernel az_net_forward launches for this many rows (csrc/net.hip, forward_partial)."""
+    names = {"1": "k_tower_split<1>", "2": "k_tower_split<2>", "4": "k_tower", "8": "k_tower_split<2,8>", "16": "k_tower16"}
+    forced = os.environ.get("AZ_TOWER_FORM", "0")
+    if forced in names:
+        return names[forced]
+    return "k_tower16" if rows > 512 else ("k_tower_split<2>" if rows > 256 else "k_tower_split<1>")
+
+
 def whole_game_block(args):
     """What the timed region (opening plies only) does not show: games played to the end.
     episode: the reference's execute_parallel_episodes (src/parallel_trainer.py:158-217) at the
@@ -507,7 +516,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_BF16_DENSE / 1e12,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_DENSE, "traffic": traffic,
                          "traffic_source": traffic_source,
-                         "kernel": "k_tower16" if args.games > 512 else ("k_tower_split<2>" if args.games > 256 else "k_tower_split<1>"),
+                         "kernel": tower_kernel_name(args.games),
                          "launch_ms": tower_ms, "launch_samples": tower_samples,
                          "flop_per_launch": flop_launch,
                          "rows_per_launch": rows_per_launch,
