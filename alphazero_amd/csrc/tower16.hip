@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256, 1) void k_tower16(TowerParams p) {
             // its four pixel tiles; the per-lane sums are then all-reduced over the 16 lanes of the
             // DPP row that holds the same channels: four rotate-and-add steps (row_ror 8, 4, 2, 1),
             // each ONE v_add_f32 with a DPP operand.  Two tiles (8 channels, 8 independent chains) at
-            // a time; lane 0 of each row stores the row's means.
+            // a time.
             // (volatile asm keeps the step-major order inside a group: left to the compiler, one
             // chain's four dependent steps run back to back and the squeeze is bound by their
             // latency.  Seven independent adds lie between a write and the DPP read of it; the
@@ -365,6 +365,26 @@ __global__ __launch_bounds__(256, 1) void k_tower16(TowerParams p) {
 #define AZ_DPP_STEP(ROR)                                                                                   \
     _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                          \
         asm volatile("v_add_f32_dpp %0, %0, %0 row_ror:" #ROR " row_mask:0xf bank_mask:0xf" : "+v"(v[i]));
+            // fc1 (128 -> 16) rides on the all-reduce: after it every lane of a row holds the row's 32
+            // channel sums, so lane (row q, column c) takes hidden unit c over those 32 channels (its
+            // weights come from LDS before the sums exist), and the four rows are added with the two
+            // lane-swap instructions: no LDS round trip for the means, none for the partial sums.
+            f32x4 w1v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                w1v[i] = *reinterpret_cast<const f32x4*>(se + c * SE_W1_PITCH + (i >> 1) * 32 + q * 8 + (i & 1) * 4);
+            // fc2's weights too (this lane's gate and shift rows; row 16 of the image is the bias b2)
+            const float* w2c = se + SE_OFF_W2 + lane;
+            float wv[4][17];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int jj = 0; jj < 17; ++jj) {
+                    wv[m][jj] = w2c[jj * 256 + 64 * m];
+                    wv[2 + m][jj] = w2c[jj * 256 + CH + 64 * m];
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            float y = 0.f;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float v[8];
@@ -380,57 +400,35 @@ __global__ __launch_bounds__(256, 1) void k_tower16(TowerParams p) {
                 AZ_DPP_STEP(4)
                 AZ_DPP_STEP(2)
                 AZ_DPP_STEP(1)
-                if (c == 0) {
-                    const f32x4 m0 = {v[0] * (1.0f / 64.0f), v[1] * (1.0f / 64.0f), v[2] * (1.0f / 64.0f), v[3] * (1.0f / 64.0f)};
-                    const f32x4 m1 = {v[4] * (1.0f / 64.0f), v[5] * (1.0f / 64.0f), v[6] * (1.0f / 64.0f), v[7] * (1.0f / 64.0f)};
-                    *reinterpret_cast<f32x4*>(scratch + g * 32 + q * 8) = m0;
-                    *reinterpret_cast<f32x4*>(scratch + g * 32 + q * 8 + 4) = m1;
-                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) y += v[i] * w1v[g * 2 + (i >> 2)][i & 3];   // channel g * 32 + q * 8 + i
             }
 #undef AZ_DPP_STEP
-            wave_lds_sync();
             const unsigned long long tsa = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-            // fc1 (128 -> 16) + ReLU: lane = (j = lane & 15, quarter = lane >> 4)
+            float hid[16];
             {
-                const float* w1 = se + c * SE_W1_PITCH + q * 32;
-                float y = 0.f;
+                typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+                // rows 0 + 1 and 2 + 3 (odd rows of one copy swapped with even rows of the other), then the two halves
+                const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+                y = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                const u32x2 t = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+                y = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+                y = fmaxf(y * (1.0f / 64.0f) + se[SE_OFF_B1 + c], 0.f);   // hidden unit c, in every row
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(w1 + i * 4);
-                    const f32x4 m = *reinterpret_cast<const f32x4*>(scratch + q * 32 + i * 4);
-                    y += w[0] * m[0] + w[1] * m[1] + w[2] * m[2] + w[3] * m[3];
-                }
-                y += __shfl_xor(y, 16);
-                y += __shfl_xor(y, 32);
-                y = fmaxf(y + se[SE_OFF_B1 + c], 0.f);
-                if (lane < 16) scratch[128 + lane] = y;  // hidden[16]
+                for (int j = 0; j < 16; ++j) hid[j] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(y), j));
             }
-            wave_lds_sync();
             const unsigned long long tsb = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
             // fc2 (16 -> 256) from the transposed weights: this lane computes the gate and the
-            // shift of channels lane and lane + 64; all 68 LDS reads are issued before the first
-            // multiply so that their latency is paid once
+            // shift of channels lane and lane + 64 (the hidden units are wave-uniform: scalar operands);
+            // all 68 LDS reads are issued before the first multiply so that their latency is paid once
             {
-                f32x4 hid[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) hid[i] = *reinterpret_cast<const f32x4*>(scratch + 128 + i * 4);
-                const float* w2c = se + SE_OFF_W2 + lane;
-                float wv[4][17];
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int jj = 0; jj < 17; ++jj) {        // row 16 of the image is the bias b2
-                        wv[m][jj] = w2c[jj * 256 + 64 * m];
-                        wv[2 + m][jj] = w2c[jj * 256 + CH + 64 * m];
-                    }
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     float g = wv[m][16], sh = wv[2 + m][16];
 #pragma unroll
                     for (int jj = 0; jj < 16; ++jj) {
-                        g += wv[m][jj] * hid[jj >> 2][jj & 3];
-                        sh += wv[2 + m][jj] * hid[jj >> 2][jj & 3];
+                        g += wv[m][jj] * hid[jj];
+                        sh += wv[2 + m][jj] * hid[jj];
                     }
                     g = __builtin_amdgcn_rcpf(1.0f + __expf(-g));  // sigmoid
                     scratch[160 + lane + 64 * m] = g;
