@@ -111,6 +111,31 @@ def test_continuous_collection_keeps_every_slot_busy(tmp_path):
     assert len(third) >= 4 * 10
 
 
+def test_the_reference_test_network_trains_through_the_fused_path(tmp_path):
+    """The network of the reference's own trainer tests (2 x 32, tests/test_trainer.py:22) on a GPU:
+    execute_parallel_episodes runs through the fused device self-play (any-width kernels), learn()
+    updates the weights, and the next episodes use the updated weights (the device copy is refreshed)."""
+    from alphazero_amd.model import AlphaZeroNet
+    from alphazero_amd.parallel_trainer import ParallelTrainer
+    torch.manual_seed(2)
+    tr = ParallelTrainer(AlphaZeroNet(num_blocks=2, num_filters=32).cuda(), device="cuda", num_parallel_games=8,
+                         num_simulations=16, checkpoint_dir=str(tmp_path), seed=7, verbose=False)
+    assert tr._fused_ok()
+    ex = tr.execute_parallel_episodes(8)
+    assert tr._selfplay is not None and tr._selfplay.engine.stats()["games_finished"] == 8
+    assert len(ex) >= 8 * 10
+    assert np.allclose(ex.policies.sum(1), 1.0, atol=1e-5)
+    assert np.all(ex.wls.sum(1) == 1.0) and np.all(ex.states[:, 2] == 1.0)
+    tr.add_examples(ex)
+    before = [p.detach().clone() for p in tr.model.parameters()]
+    stats = tr.learn(epochs=1, batch_size=32)
+    assert np.isfinite(stats["loss"])
+    assert any(not torch.equal(a, b) for a, b in zip(before, tr.model.parameters()))
+    assert tr._weights_changed
+    again = tr.execute_parallel_episodes(4)
+    assert not tr._weights_changed and len(again) >= 4 * 10
+
+
 def test_learn_on_the_gpu_reproduces_the_reference_weights(tmp_path):
     """The reference trainer's learn(epochs=2, batch_size=16) on 48 synthetic examples from fixed
     seeds (tests/golden/train_tier.npz, recorded on CPU) against the drop-in's learn() on
