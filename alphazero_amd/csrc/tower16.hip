@@ -22,8 +22,9 @@
 //     8 consecutive channels of one chunk: tile nt, row 4 q + i  <->  channel
 //     (nt >> 1) * 32 + q * 8 + (nt & 1) * 4 + i.  The weight images carry that order
 //     (pack_conv3x3_16 in net.hip);
-//   * built with the accumulators in AGPRs (the compiler's default; see build.sh), and the block
-//     loop runs the two convs of a block per pass, so a conv's parity is a literal.
+//   * the block loop runs the two convs of a block per pass, so a conv's parity is a literal (weight
+//     buffer and bias row are immediates, the registers of the two epilogue kinds never meet in a
+//     phi); the register form of the accumulators is chosen in build.sh.
 #include "tower_common.h"
 
 namespace az {
