@@ -22,7 +22,7 @@ $HIPCC $COMMON -mllvm -amdgpu-mfma-vgpr-form=1 -DAZ_SPLIT_STAMPS=${AZ_SPLIT_STAM
 # faster; with the loop over blocks (literal conv parity, no phi copies) it parks the residual and the tap
 # addresses in AGPRs instead, the loops are clean in both forms and the VGPR form saves the 128 accumulator reads
 # of every epilogue: 0.877 against 0.886 of k_tower's time per forward.  Check the tap loop's instruction mix
-# (v_accvgpr_*, s_nop 7) after any change to tower16.hip.
+# (v_accvgpr_*, s_nop 7) after any change to tower16.hip: python tools/tower16_isa_check.py [--agpr].
 $HIPCC $COMMON ${T16_FLAGS--mllvm -amdgpu-mfma-vgpr-form=1} -Rpass-analysis=kernel-resource-usage -c tower16.hip -o $OBJ/tower16.o 2> $OBJ/tower16.remarks & pids+=($!)
 $HIPCC $COMMON -c tower_any.hip -o $OBJ/tower_any.o & pids+=($!)
 g++ -O2 -fPIC -std=c++17 -c core.cpp -o $OBJ/core.o & pids+=($!)
