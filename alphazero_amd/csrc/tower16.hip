@@ -41,19 +41,25 @@ constexpr int L16_SE = L16_BIAS + 1024;             // 133120
 constexpr int L16_TOTAL = L16_SE + SE_BYTES;        // 159744
 
 // one 1 KB piece of an LDS-DMA copy whose global and LDS bases are both passed 4 KB in (the
-// immediate offset, -4096 ... 3072, is added to both).  M0 is written right before its use and not
-// restored: the compiler keeps nothing in it (a reserved register, set before each of its own uses).
+// immediate offset, -4096 ... 3072, is added to both).  M0 is not restored: the compiler keeps
+// nothing in it (a reserved register, set before each of its own uses).
 #ifndef AZ_T16_DIAG
 #define AZ_T16_DIAG 0
 #endif
-template <int OFF>
+template <int OFF, bool SET_M0 = false>
 __device__ __forceinline__ void glds16_piece(const void* gsrc_plus_4k, uint32_t lds_dst_plus_4k) {
     if (AZ_T16_DIAG >= 2) return;
     if (AZ_T16_DIAG == 1 && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) != 0) return;
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2"
-                 :
-                 : "v"(gsrc_plus_4k), "s"(lds_dst_plus_4k), "n"(OFF)
-                 : "memory");
+    // The eight pieces of a tap share one M0 (the immediate offset moves both addresses): only the
+    // first piece writes it.  Nothing else in this kernel writes M0 except the bias / SE copies, which
+    // put the old value back; volatile asm statements keep their order.
+    if (SET_M0)
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2"
+                     :
+                     : "v"(gsrc_plus_4k), "s"(lds_dst_plus_4k), "n"(OFF)
+                     : "memory");
+    else
+        asm volatile("global_load_lds_dwordx4 %0, off offset:%1" : : "v"(gsrc_plus_4k), "n"(OFF) : "memory");
 }
 
 struct Frags16 {
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(256, 1) void k_tower16(TowerParams p) {
                 if (AZ_T16_DIAG < 4) f1.x[0] = lds_read_frag(lds, aaddr[tap][0] ^ k16[1]);
                 if (AZ_T16_DIAG < 4) f1.x[1] = lds_read_frag(lds, aaddr[tap][1] ^ k16[1]);
                 mma16<0, 1>(acc, f0); group(2);
-                glds16_piece<-4096>(src, dst);
+                glds16_piece<-4096, true>(src, dst);
                 if (AZ_T16_DIAG < 4) f1.x[2] = lds_read_frag(lds, aaddr[tap][2] ^ k16[1]);
                 if (AZ_T16_DIAG < 4) f1.x[3] = lds_read_frag(lds, aaddr[tap][3] ^ k16[1]);
                 mma16<1, 2>(acc, f0); group(2);
