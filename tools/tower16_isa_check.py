@@ -4,9 +4,9 @@ The register allocator's treatment of this kernel changes with unrelated edits: 
     python tools/tower16_isa_check.py            # the form build.sh ships (accumulators in VGPRs)
     python tools/tower16_isa_check.py --agpr     # the compiler's default form
 
-A healthy tap loop is a basic block of 1,152 MFMAs with about 2,200 instructions: 440 ds_read_b128, 72-79
-global_load_lds_dwordx4, about 30 v_accvgpr_read_b32 (tap addresses parked in AGPRs), no v_accvgpr_write_b32 to speak
-of, s_nop cycles around 100, and the kernel reports no spill."""
+A healthy tap loop is a basic block of 1,152 MFMAs with 2,080 to 2,150 instructions: 440 ds_read_b128, 72-79
+global_load_lds_dwordx4, about 30 v_accvgpr_read_b32 (tap addresses parked in AGPRs), at most a few
+v_accvgpr_write_b32, 40 to 65 s_nop cycles, and the kernel reports no spill."""
 import collections
 import os
 import re
