@@ -10,7 +10,7 @@ namespace az {
 constexpr uint32_t NODE_NONE = 0xFFFFFFFFu;
 constexpr int MAX_DEPTH = 256;          // longest selection path (a game lasts < 200 plies)
 constexpr uint32_t FLAG_UNIFORM64 = 1;  // children hold the float64 prior 1/k (src/mcts.py:277-278)
-constexpr int ERR_POOL = 1, ERR_DEPTH = 2, ERR_HISTORY = 4, ERR_NODE = 8;
+constexpr int ERR_POOL = 1, ERR_DEPTH = 2, ERR_HISTORY = 4, ERR_NODE = 8, ERR_NOROOT = 16;
 
 // Device pointers + scalars, passed to kernels by value.
 struct EngineView {
@@ -133,6 +133,19 @@ struct SelfplayView {
     unsigned long long* stat;  // [0] moves, [1] games finished
 };
 
+// Buffers of the leaf-parallel latency search (leafpar.hip), one row per pending descent.
+struct LeafParView {
+    uint64_t *mine, *theirs;   // [rows] canonical leaf positions = the network's input
+    uint32_t* node;            // [rows]
+    int8_t* turn;              // [rows]
+    uint16_t* len;             // [rows] path length
+    uint8_t* kind;             // [rows] 0: evaluate, 1: terminal, 2: same leaf as row first[row], 3: no descent
+    uint8_t* first;            // [rows]
+    float* tv;                 // [rows] terminal value
+    uint32_t* path;            // [rows][MAX_DEPTH]
+    int32_t* slots;            // [games]
+};
+
 }  // namespace az
 
 struct az_engine {
@@ -162,6 +175,9 @@ struct az_engine {
     int32_t* n_rows_dev = nullptr;   // rows of the last network launch
     unsigned long long* rows_total_dev = nullptr;  // rows of all network launches of the fused search
     uint64_t move_calls = 0;
+    // leaf-parallel latency search (leafpar.hip): allocated on first use, freed with the engine
+    az::LeafParView lp{};
+    bool lp_ready = false;
 };
 
 namespace az {

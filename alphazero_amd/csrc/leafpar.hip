@@ -19,8 +19,6 @@
 //
 // Compiled with -ffp-contract=off like the other tree code (q + u stays two rounded operations).
 #include <type_traits>
-#include <utility>
-#include <vector>
 
 #include "az_engine.h"
 #include "head_dev.h"
@@ -33,18 +31,6 @@ constexpr uint32_t VL_ONE = 1u << 24, VL_MASK = 0xFF000000u;
 constexpr int LP_MAX_K = 32;          // descents per game and batch
 constexpr int LP_MAX_ROWS = 256;      // network rows per batch (games x K)
 
-struct LeafParView {
-    uint64_t *mine, *theirs;   // [rows] canonical leaf positions = the network's input
-    uint32_t* node;            // [rows]
-    int8_t* turn;              // [rows]
-    uint16_t* len;             // [rows] path length
-    uint8_t* kind;             // [rows] 0: evaluate, 1: terminal, 2: same leaf as row first[row]
-    uint8_t* first;            // [rows]
-    float* tv;                 // [rows] terminal value
-    uint32_t* path;            // [rows][MAX_DEPTH]
-    int32_t* slots;            // [games]
-};
-
 // one wave per game: K descents, one after the other
 __global__ __launch_bounds__(64) void k_lp_select(EngineView E, LeafParView L, int kmax, int K) {
     __shared__ uint32_t s_leaf[LP_MAX_K];
@@ -53,6 +39,10 @@ __global__ __launch_bounds__(64) void k_lp_select(EngineView E, LeafParView L, i
     const size_t pool = pool_base(E, g);
     const SelectStart st = load_select_start(E, g);
     const float cp32 = (float)E.c_puct;
+    if (st.root == NODE_NONE) {   // nothing to descend from: no row of this game holds a descent
+        if (lane == 0) atomicOr(E.err, ERR_NOROOT);
+        K = 0;
+    }
     for (int j = 0; j < K; ++j) {
         const int row = blockIdx.x * kmax + j;
         uint32_t* path = L.path + (size_t)row * MAX_DEPTH;
@@ -151,6 +141,7 @@ __global__ __launch_bounds__(64) void k_lp_finish(EngineView E, LeafParView L, F
     for (int j = 0; j < K; ++j) {
         const int row = blockIdx.x * kmax + j;
         const int kind = L.kind[row];
+        if (kind == 3) continue;   // the game had no root (reported by k_lp_select)
         float v;
         if (kind == 0) {
             float pr[3];
@@ -188,29 +179,20 @@ __global__ __launch_bounds__(64) void k_lp_finish(EngineView E, LeafParView L, F
 
 using namespace az;
 
-struct LeafParBuffers {
-    LeafParView v{};
-    std::vector<void*> allocs;
-    ~LeafParBuffers() { for (void* p : allocs) (void)hipFree(p); }
-};
-
-// one set of buffers per engine, made on first use and released with the library (a handful of
-// engines exist per process: the drop-in MCTS keeps a pool of them)
+// one set of buffers per engine, made on first use and freed by az_engine_destroy with the
+// engine's other device memory
 static int lp_buffers(az_engine* e, LeafParView* out) {
-    static std::vector<std::pair<az_engine*, LeafParBuffers*>> table;
-    for (auto& it : table)
-        if (it.first == e) { *out = it.second->v; return AZ_OK; }
-    LeafParBuffers* b = new LeafParBuffers();
+    if (e->lp_ready) { *out = e->lp; return AZ_OK; }
+    LeafParView v{};
     auto alloc = [&](auto*& ptr, size_t count) -> int {
         void* p = nullptr;
         AZ_HIP(hipMalloc(&p, count * sizeof(*ptr)));
-        b->allocs.push_back(p);
+        e->allocs.push_back(p);
         AZ_HIP(hipMemset(p, 0, count * sizeof(*ptr)));
         ptr = (std::remove_reference_t<decltype(ptr)>)p;
         return AZ_OK;
     };
     int rc = AZ_OK;
-    LeafParView& v = b->v;
     if (rc == AZ_OK) rc = alloc(v.mine, LP_MAX_ROWS);
     if (rc == AZ_OK) rc = alloc(v.theirs, LP_MAX_ROWS);
     if (rc == AZ_OK) rc = alloc(v.node, LP_MAX_ROWS);
@@ -221,9 +203,10 @@ static int lp_buffers(az_engine* e, LeafParView* out) {
     if (rc == AZ_OK) rc = alloc(v.tv, LP_MAX_ROWS);
     if (rc == AZ_OK) rc = alloc(v.path, (size_t)LP_MAX_ROWS * MAX_DEPTH);
     if (rc == AZ_OK) rc = alloc(v.slots, LP_MAX_ROWS);
-    if (rc != AZ_OK) { delete b; return rc; }
-    table.emplace_back(e, b);
-    *out = b->v;
+    if (rc != AZ_OK) return rc;   // what was allocated stays in e->allocs and goes with the engine
+    e->lp = v;
+    e->lp_ready = true;
+    *out = v;
     return AZ_OK;
 }
 

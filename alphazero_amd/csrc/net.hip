@@ -1181,7 +1181,7 @@ struct az_net {
     unsigned long long* stamps = nullptr;  // diagnostic cycle stamps (AZ_TOWER_STAMPS=1)
     // optional HIP-event timing of the tower kernel (az_net_set_timing)
     bool timing = false;
-    int tower_form = 0;   // 0: chosen by batch size; 1, 2, 4, 8: forced (az_net_set_tower_form)
+    int tower_form = 0;   // 0: chosen by batch size; 1, 2, 4, 8, 16: forced (az_net_set_tower_form)
     int64_t launches = 0;
     int ev_used = 0;
     std::vector<hipEvent_t> ev0, ev1;
@@ -1668,7 +1668,7 @@ static int forward_partial(az_net* n, int32_t B, const uint64_t* mine_dev, const
     }
     // form of the tower: whole positions per wave from 513 positions up (k_tower16; 4 = k_tower, the
     // same tiling on the 32x32x16 MFMA shape), channel-split waves
-    // below (az_net_set_tower_form or AZ_TOWER_FORM force one; with stamps on the default is k_tower, whose stamps are always compiled in)
+    // below (az_net_set_tower_form or AZ_TOWER_FORM force one; with stamps on the default is k_tower16 at every batch size: the whole-position kernels are the ones that record stamps)
     static const int env_form = getenv("AZ_TOWER_FORM") ? atoi(getenv("AZ_TOWER_FORM")) : 0;
     const int forced = n->tower_form ? n->tower_form : env_form;
     int form = forced ? forced : (B <= 256 ? 1 : (B <= 512 ? 2 : 16));

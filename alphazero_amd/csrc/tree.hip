@@ -423,6 +423,8 @@ int az::check_engine_error(az_engine* e, hipStream_t s) {
     if (flag & ERR_POOL) AZ_FAIL(AZ_ERR_CAPACITY, "node pool exhausted (pool_nodes_per_game = %u)", e->v.cap);
     if (flag & ERR_DEPTH) AZ_FAIL(AZ_ERR_CAPACITY, "selection path deeper than %d", MAX_DEPTH);
     if (flag & ERR_NODE) AZ_FAIL(AZ_ERR_ARG, "az_engine_set_roots: a game slot or node index was out of range");
+    if (flag & ERR_NOROOT)
+        AZ_FAIL(AZ_ERR_STATE, "az_engine_search_leaf_parallel: a game has no root (az_engine_search with 0 simulations makes one)");
     if (flag & ERR_HISTORY)
         AZ_FAIL(AZ_ERR_CAPACITY, "sample queue full or a game longer than %d plies: samples were dropped "
                                  "(drain the queue before it holds %u samples)", MAX_PLIES, e->sp.q_cap);

@@ -287,7 +287,8 @@ int az_engine_search(az_engine* e, int32_t num_simulations, int32_t add_noise, v
  * evaluation.  Visit counts and value sums stay exact sums, but the order of the descents is
  * not the reference's: results differ from az_engine_search for leaf_batch > 1 (use that call
  * for the reference's results).  Roots must exist (az_engine_search with 0 simulations expands
- * them).  n * leaf_batch <= 256 rows, leaf_batch <= 32; the attached network must take that
+ * them); a game without one makes no descent and the call fails with AZ_ERR_STATE.
+ * n * leaf_batch <= 256 rows, leaf_batch <= 32; the attached network must take that
  * many rows.  No counterpart in the reference. */
 int az_engine_search_leaf_parallel(az_engine* e, int32_t n, const int32_t* slots_host, int32_t num_simulations,
                                    int32_t leaf_batch, void* stream);

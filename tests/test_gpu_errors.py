@@ -106,6 +106,36 @@ def test_capacity_errors_are_reported_once_and_the_engine_stays_usable():
     e.pool_usage()
 
 
+def test_leaf_parallel_search_refuses_a_game_without_a_root():
+    """az_engine_search_leaf_parallel descends from existing roots; a slot that has none is
+    reported as a call-sequence error (no descent is made for it, no tree is touched), and the
+    same call works once the root exists.  Engines come and go: each one carries its own buffers."""
+    from alphazero_amd._lib import AzError
+    from alphazero_amd.engine import Engine
+    from alphazero_amd.model import AlphaZeroNet, HipInference
+    torch.manual_seed(3)
+    inf = HipInference(AlphaZeroNet(num_blocks=1, num_filters=128).eval(), max_batch=64)
+    for _ in range(3):
+        e = Engine(4, pool_nodes_per_game=1 << 12)
+        e.attach_net(inf)
+        e.reset_all()
+        with pytest.raises(AzError, match="has no root"):
+            e.search_leaf_parallel(np.array([0, 2], np.int32), 16, 8)
+        assert e.root_counts().tolist() == [-1, -1, -1, -1]
+        e.search(0)                                   # expands the roots
+        e.search_leaf_parallel(np.array([0, 2], np.int32), 16, 8)
+        q = e.root_children(2)
+        assert q["root_N"] == 16 and int(q["N"].sum()) == 16
+        assert e.root_children(1)["root_N"] == 0      # a slot that was not named is left alone
+        with pytest.raises(AzError, match="appears twice"):
+            e.search_leaf_parallel(np.array([1, 1], np.int32), 4, 2)
+        with pytest.raises(AzError, match="is not in 1"):
+            e.search_leaf_parallel(np.arange(4, dtype=np.int32), 4, 33)
+        with pytest.raises(AzError, match="the network takes 64 rows"):
+            e.search_leaf_parallel(np.arange(4, dtype=np.int32), 4, 32)
+        e.close()
+
+
 def test_full_sample_queue_drops_whole_games_and_keeps_the_count_consistent():
     """Queue space is handed out in game order by a scan; a game that does not fit is dropped
     whole, the queue length never counts samples that were not written, and draining the
