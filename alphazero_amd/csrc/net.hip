@@ -1712,6 +1712,8 @@ int az::net_forward_partial(az_net* n, int32_t B, const uint64_t* mine_dev, cons
     return forward_partial(n, B, mine_dev, theirs_dev, rows, n->own(), s);
 }
 
+int az::net_device(const az_net* n) { return n->device; }
+
 az::FinishParams az::net_finish_params(az_net* n, int32_t B, const int32_t* n_rows) {
     return finish_params(n, B, n->own(), n_rows);
 }

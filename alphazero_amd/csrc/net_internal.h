@@ -30,4 +30,6 @@ int net_forward_full(az_net* n, int32_t B, const uint64_t* mine_dev, const uint6
                      float* wl_logits_dev, hipStream_t s);
 // what dev_head_finish needs to turn those partial sums into probabilities / values
 FinishParams net_finish_params(az_net* n, int32_t B, const int32_t* n_rows);
+// HIP device ordinal the network's weights and buffers live on
+int net_device(const az_net* n);
 }  // namespace az

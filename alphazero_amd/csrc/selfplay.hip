@@ -341,6 +341,9 @@ extern "C" int az_engine_attach_net(az_engine* e, az_net* n) {
     AZ_CHECK_ARG(e && n, "az_engine_attach_net: null argument");
     AZ_CHECK_ARG(az_net_max_batch(n) >= e->v.B, "az_engine_attach_net: network max_batch %d < n_games %d",
                  az_net_max_batch(n), e->v.B);
+    // the fused search hands the engine's device arrays to the network's kernels
+    AZ_CHECK_ARG(az::net_device(n) == e->device, "az_engine_attach_net: the network lives on device %d, the engine on device %d",
+                 az::net_device(n), e->device);
     const int rc = selfplay_alloc(e);
     if (rc == AZ_OK) e->net = n;  // a network counts as attached only with the self-play buffers in place
     return rc;
