@@ -58,6 +58,8 @@ if __name__ == "__main__":
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--mask", action="store_true")
     ap.add_argument("--planes", action="store_true")
+    ap.add_argument("--host", action="store_true", help="also time the host-to-host path: numpy arrays in through "
+                    "alphazero_amd.game.movegen_encode, legal3 / status (and the mask) back as numpy arrays, PCIe copies included")
     a = ap.parse_args()
     w, b, t = random_positions(min(a.n, 4_000_000), seed=1)
     if a.n > w.numel():                      # tile up to the requested size
@@ -88,3 +90,22 @@ if __name__ == "__main__":
     print(f"n={n} mask={a.mask} planes={a.planes}: {us:.2f} us/launch, {n / us:.1f} Mpos/s, "
           f"{bytes_per} B/pos algorithmic -> {n * bytes_per / us / 1e3:.1f} GB/s "
           f"({n * bytes_per / us / 1e3 / 8000 * 100:.1f}% of 8 TB/s)")
+    if a.host:
+        import time
+        wn, bn, tn = w.cpu().numpy().view(np.uint64), b.cpu().numpy().view(np.uint64), t.cpu().numpy()
+
+        def host_run():
+            r = movegen_encode(wn, bn, tn, want_mask=a.mask, want_planes=False)
+            out = [r["legal3"].cpu().numpy(), r["status"].cpu().numpy()]
+            if a.mask:
+                out.append(r["mask"].cpu().numpy())
+            return out
+        host_run()
+        t0 = time.perf_counter()
+        reps = max(1, min(20, a.iters))
+        for _ in range(reps):
+            host_run()
+        dt = (time.perf_counter() - t0) / reps
+        hb = 42 + (192 if a.mask else 0)
+        print(f"host arrays in, host arrays out (pageable memory, copies included): {dt * 1e3:.2f} ms per call, "
+              f"{n / dt / 1e6:.1f} Mpos/s, {n * hb / dt / 1e9:.1f} GB/s over PCIe")
