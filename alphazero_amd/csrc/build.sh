@@ -5,8 +5,16 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 OUT=../libazamd.so
 OBJ=../../build/obj
-mkdir -p "$OBJ"
 COMMON="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-result"
+# HOSTSAN=1: the same library with the HOST code under UndefinedBehaviorSanitizer in trap mode (no
+# runtime to link or preload: undefined behaviour in the host code ends the process with SIGILL), the
+# device code unchanged.  Run the GPU suite on it with AZAMD_LIB=alphazero_amd/libazamd_hostsan.so.
+if [ "${HOSTSAN:-0}" = "1" ]; then
+  OUT=../libazamd_hostsan.so
+  OBJ=../../build/obj_hostsan
+  COMMON="$COMMON -Xarch_host -fsanitize=undefined -Xarch_host -fsanitize-trap=undefined"
+fi
+mkdir -p "$OBJ"
 pids=()
 # tree/movegen: exact float32 semantics -> no FMA contraction
 $HIPCC $COMMON -ffp-contract=off -c tree.hip -o $OBJ/tree.o & pids+=($!)
@@ -25,7 +33,7 @@ $HIPCC $COMMON -mllvm -amdgpu-mfma-vgpr-form=1 -DAZ_SPLIT_STAMPS=${AZ_SPLIT_STAM
 # (v_accvgpr_*, s_nop 7) after any change to tower16.hip: python tools/tower16_isa_check.py [--agpr].
 $HIPCC $COMMON ${T16_FLAGS--mllvm -amdgpu-mfma-vgpr-form=1} -Rpass-analysis=kernel-resource-usage -c tower16.hip -o $OBJ/tower16.o 2> $OBJ/tower16.remarks & pids+=($!)
 $HIPCC $COMMON -c tower_any.hip -o $OBJ/tower_any.o & pids+=($!)
-g++ -O2 -fPIC -std=c++17 -c core.cpp -o $OBJ/core.o & pids+=($!)
+g++ -O2 -fPIC -std=c++17 ${HOSTSAN:+-fsanitize=undefined -fsanitize-undefined-trap-on-error} -c core.cpp -o $OBJ/core.o & pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJ/*.o
 echo "built $(readlink -f $OUT)"
