@@ -285,15 +285,18 @@ def test_graphed_learn_matches_the_eager_step(tmp_path):
     """ParallelTrainer(graph_step=True): every full batch of learn() is replayed from captured HIP
     graphs (the regime of a data-parallel rank's small slice, where the step is launch bound); the
     ragged last batch and the first steps run eagerly.  Same seeds, same examples as an eager
-    trainer, two learn() calls with a learning-rate change between them.  The two runs cannot
-    agree bit for bit: capturable Adam rounds differently in the seventh digit, MIOpen's
-    weight-gradient kernels are not deterministic, and a pre-activation within that noise of zero
-    flips its ReLU mask, which changes single gradient elements by percents (measured: gradients
-    5 % apart on one element at the second step, weights 1e-7 apart before it).  What must hold:
-    the same losses to 5e-3, and after 52 steps the graphed run no further from eager steps with
-    the same (capturable) Adam than twice the distance that optimiser's rounding alone puts
-    between two eager runs; a checkpoint written by the graphed trainer loads into an eager one on
-    the CPU."""
+    trainer.  The two runs cannot agree bit for bit: capturable Adam rounds differently in the
+    seventh digit, MIOpen's weight-gradient kernels are not deterministic, and a pre-activation
+    within that noise of zero flips its ReLU mask, which changes single gradient elements by
+    percents; over tens of steps that divergence grows like that of any two float32 training runs
+    (measured after 52 steps: relative L2 distance 1e-2 to 3e-2 between any two of the three runs
+    below, in no fixed order).  So the arithmetic of the replayed step is checked where the
+    divergence has had no time to grow: after six steps (three eager warm-up steps, the capture,
+    two more replays) the graphed weights are within 1e-3 of eager steps with the same optimiser
+    arithmetic - a skipped, doubled or stale step would be 1e-2 away.  The long run (two learn()
+    calls with a learning-rate change between them) then has to keep the losses together, stay
+    inside the divergence two eager runs show, and re-capture the update graph at the new
+    learning rate; a checkpoint written by the graphed trainer loads into an eager one on the CPU."""
     from alphazero_amd.model import AlphaZeroNet
     from alphazero_amd.parallel_trainer import ExampleArrays, ParallelTrainer
     rs = np.random.RandomState(3)
@@ -303,40 +306,55 @@ def test_graphed_learn_matches_the_eager_step(tmp_path):
     pol /= pol.sum(1, keepdims=True)
     wls = np.tile(np.array([[1.0, 0.0], [0.0, 1.0]], np.float32), (n // 2, 1))
 
-    def run(graph, capturable=False):
+    def run(graph, capturable=False, n_used=n, calls=2, epochs=2, tag=""):
         torch.manual_seed(11)
         model = AlphaZeroNet(num_blocks=2, num_filters=32).cuda()
-        tr = ParallelTrainer(model, device="cuda", checkpoint_dir=str(tmp_path / ("g" if graph else "e")), verbose=False,
+        tr = ParallelTrainer(model, device="cuda", checkpoint_dir=str(tmp_path / (("g" if graph else "e") + tag)), verbose=False,
                              graph_step=graph)
         if capturable:
             from alphazero_amd.distributed import make_capturable
             make_capturable(tr.optimizer)
-        tr.add_examples(ExampleArrays(states, pol, wls))
+        tr.add_examples(ExampleArrays(states[:n_used], pol[:n_used], wls[:n_used]))
         out = []
-        for _ in range(2):
+        for _ in range(calls):
             torch.manual_seed(5)
-            out.append(tr.learn(epochs=2, batch_size=32))      # 400 augmented examples: 12 full batches + one of 16
+            out.append(tr.learn(epochs=epochs, batch_size=32))
         return tr, out
 
+    def distance(x, y):
+        with torch.no_grad():
+            px = torch.cat([t.float().reshape(-1) for t in x.model.parameters()])
+            py = torch.cat([t.float().reshape(-1) for t in y.model.parameters()])
+            return float((px - py).norm() / px.norm()), float((px - py).abs().max())
+
+    # ---- six steps: 96 examples, mirrored to 192 = six full batches of 32, one epoch
+    short_e, _ = run(False, capturable=True, n_used=96, calls=1, epochs=1, tag="s")
+    short_g, _ = run(True, n_used=96, calls=1, epochs=1, tag="s")
+    step = short_g._graphed[32]
+    assert step.graph_a is not None and step.graph_b is not None and step.steps_seen == 6
+    d_short = distance(short_e, short_g)
+    print(f"after 6 steps (3 replayed): relative L2 distance / largest single difference {d_short[0]:.2e} / {d_short[1]:.2e}")
+    assert d_short[0] < 1e-3, d_short
+
+    # ---- 52 steps over two learn() calls: 400 augmented examples = 12 full batches + one of 16 per epoch
     eager, stats_e = run(False)
     same_adam, _ = run(False, capturable=True)        # eager steps with the optimiser arithmetic the graphs use
     graphed, stats_g = run(True)
     assert graphed._graphed and all(g.graph_a is not None for g in graphed._graphed.values())
     for a, b in zip(stats_e, stats_g):
         for k in ("loss", "pi", "wl"):
-            assert abs(a[k] - b[k]) < 5e-3, (k, a[k], b[k])
-    def distance(x, y):
-        px = torch.cat([t.float().reshape(-1) for t in x.model.parameters()])
-        py = torch.cat([t.float().reshape(-1) for t in y.model.parameters()])
-        return float((px - py).norm() / px.norm()), float((px - py).abs().max())
+            assert abs(a[k] - b[k]) < 2e-2, (k, a[k], b[k])
     d_graph, d_adam = distance(same_adam, graphed), distance(eager, same_adam)
     print(f"after 52 steps, relative L2 distance / largest single difference of the weights: graphed against eager steps "
           f"with the same optimiser arithmetic {d_graph[0]:.2e} / {d_graph[1]:.2e}; those against the reference's Adam "
           f"{d_adam[0]:.2e} / {d_adam[1]:.2e}")
-    # replaying the step from graphs must not move the weights further from the eager run than the
-    # optimiser's own rounding does (both are the same chaotic divergence), with a floor for runs
-    # in which no mask happened to flip
-    assert d_graph[0] <= max(2e-3, 2.0 * d_adam[0])
+    # both distances are samples of the same chaotic divergence (either may be the larger one): the
+    # graphed run has to stay in its range, far below what a wrong step would give
+    assert d_graph[0] < 0.1 and d_adam[0] < 0.1, (d_graph, d_adam)
+    # the schedule stepped after the first learn(): the update graph in use was captured at the new rate
+    lr_now = float(graphed.optimizer.param_groups[0]["lr"])        # after the second scheduler step
+    lr_captured = graphed._graphed[32].lr                          # the rate of the second learn() call
+    assert lr_captured is not None and lr_now < lr_captured < 1e-3, (lr_now, lr_captured)
     graphed.save_iteration_checkpoint(1)
     other = ParallelTrainer(AlphaZeroNet(num_blocks=2, num_filters=32), device="cpu", checkpoint_dir=str(tmp_path / "g"),
                             verbose=False)
