@@ -241,6 +241,46 @@ def secondary_block(blocks):
                            "tower_frac": (tower_flop_per_position(blocks) * B / (tower_ms * 1e-3) / PEAK_BF16_DENSE) if tower_ms else None,
                            "forwards_timed": iters}
     inf.close()
+    # the same module through stock PyTorch-ROCm (MIOpen / hipBLASLt) on this GPU, as the reference would run it
+    # on a GPU device (src/mcts.py:245-253: float32 planes in, eval mode, no_grad, softmaxes): float32 and, for
+    # scale, bf16 autocast.  A reported baseline beside the HIP figure, not part of any product path.
+    try:
+        torch.manual_seed(0)
+        net = AlphaZeroNet(num_blocks=blocks, num_filters=128).eval().to(dev)
+        x = r["planes"].to(dev)
+        res = {}
+        searched = torch.backends.cudnn.benchmark
+        for label, dtype, search in (("float32", None, False), ("bf16_autocast", torch.bfloat16, False),
+                                     ("float32_solver_search", None, True), ("bf16_autocast_solver_search", torch.bfloat16, True)):
+            torch.backends.cudnn.benchmark = search       # True: MIOpen times its solvers per layer shape first
+            def fwd():
+                with torch.no_grad():
+                    if dtype is None:
+                        pl, wl = net(x)
+                    else:
+                        with torch.autocast(device_type="cuda", dtype=dtype):
+                            pl, wl = net(x)
+                    return torch.softmax(pl.float(), 1), torch.softmax(wl.float(), 1)
+            for _ in range(3):
+                fwd()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                fwd()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            res[label] = {"ms_per_forward": ms, "positions_per_sec": B / (ms * 1e-3),
+                          "achieved_TFLOPs": flop / (ms * 1e-3) / 1e12}
+        torch.backends.cudnn.benchmark = searched
+        best = min(v["ms_per_forward"] for v in res.values())
+        res["hip_speedup_over_float32"] = res["float32"]["ms_per_forward"] / (sec * 1e3)
+        res["hip_speedup_over_the_fastest_of_these"] = best / (sec * 1e3)
+        out["forward_4096"]["torch_rocm_same_gpu"] = res
+        del net, x
+    except Exception as exc:
+        out["forward_4096"]["torch_rocm_same_gpu"] = {"error": repr(exc)}
     return out
 
 
