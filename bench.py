@@ -560,7 +560,11 @@ def main():
                          "launch_ms": tower_ms, "launch_samples": tower_samples,
                          "flop_per_launch": flop_launch,
                          "rows_per_launch": rows_per_launch,
-                         "mean_search_depth": depth},
+                         "mean_search_depth": depth,
+                         # the whole job against the same peak: evaluated positions/s x FLOP per position of the
+                         # whole network (tower + heads), tree kernels, head GEMM and launch gaps included in the time
+                         "end_to_end_achieved": evals / dt * network_flop_per_position(args.blocks) / 1e12,
+                         "end_to_end_frac": evals / dt * network_flop_per_position(args.blocks) / (PEAK_BF16_DENSE * world)},
         }
         if exchange is not None:
             out["exchange"] = exchange
