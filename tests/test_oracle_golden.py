@@ -293,3 +293,55 @@ def test_oracle_movegen_matches_the_baseline_engine(golden_dir):
     d = np.load(os.path.join(golden_dir, "baseline_movegen_tier.npz"))
     legal3, _, _, status = orc.movegen_batch(d["white"], d["black"], d["turn"], want_mask=False, want_planes=False)
     check_against_baseline_engine(d, legal3, status)
+
+
+def test_leaf_parallel_model_with_one_descent_per_batch_is_the_exact_search():
+    """tests/leafpar_model.py (the CPU statement of the opt-in leaf-parallel mode the GPU test
+    compares the device with) degenerates to the reference's search when a batch holds one
+    descent: no count is ever in flight during a selection.  Root statistics must then equal the
+    oracle's - which the fixtures above pin to the reference - bit for bit, with plain and noisy
+    roots, including positions whose table rows force the uniform-prior fallback."""
+    import leafpar_model as lpm
+    from fake_net import TableEvaluator
+    ev = TableEvaluator()
+
+    def evaluate(ps):
+        planes = np.stack([orc.encode_state(p) for p in ps])
+        return ev(planes)
+
+    w, b, t, win = orc.random_positions(3000, 77)
+    rs = np.random.RandomState(3)
+    checked = 0
+    for case in range(12):
+        while True:
+            i = int(rs.randint(0, 3000))
+            p = orc.make_pos(w[i], b[i], t[i], win[i])
+            if not orc.is_terminal(p):
+                break
+        S = int(rs.choice([1, 7, 60, 150]))
+        noisy = bool(case % 2)
+        m = orc.OracleMCTS(1, c_puct=1.5)
+        m.set_game(0, p)
+        k = len(orc.legal_actions(p))
+        noise = None
+        if noisy:
+            noise = np.zeros((1, 48), np.float64)
+            noise[0, :k] = rs.dirichlet([0.35] * k)
+        m.search(ev, S, noise=noise)
+        want = m.root_children(0)
+        root = lpm.MNode()
+        pr, _ = evaluate([p])
+        lpm.expand(root, p, pr[0])
+        if noisy:
+            m0 = orc.OracleMCTS(1, c_puct=1.5)          # the mixed float64 priors as the oracle holds them
+            m0.set_game(0, p)
+            m0.search(ev, 0, noise=noise)
+            for c, p64 in zip(root.children, m0.root_children(0)["P"]):
+                c.P64 = float(p64)
+        lpm.search(root, p, evaluate, S, 1, c_puct=1.5, noisy_root=noisy)
+        assert root.N == want["root_N"] == S
+        assert root.actions == list(want["actions"])
+        assert [c.N for c in root.children] == list(want["N"])
+        assert [np.float32(c.W).view(np.uint32) for c in root.children] == list(want["W"].view(np.uint32))
+        checked += 1
+    assert checked == 12
