@@ -281,6 +281,33 @@ def secondary_block(blocks):
         del net, x
     except Exception as exc:
         out["forward_4096"]["torch_rocm_same_gpu"] = {"error": repr(exc)}
+    # single-game search as the reference's arena and web front end run it (src/arena.py:248-265, src/web.py:447-470:
+    # MCTS.search on a fresh root, 200 simulations, no noise) through the drop-in MCTS: the exact search
+    # (leaf_batch 1) and the opt-in leaf-parallel mode, host loop included
+    try:
+        from alphazero_amd.game import BreakthroughGame
+        from alphazero_amd.mcts import MCTS
+        torch.manual_seed(0)
+        lat_model = AlphaZeroNet(num_blocks=blocks, num_filters=128).to(dev).eval()
+        lat = {}
+        for k in (1, 16):
+            m = MCTS(lat_model, num_simulations=200, device=str(dev), leaf_batch=k)
+            m.search(BreakthroughGame())                   # warm-up: engine, weight upload
+            torch.cuda.synchronize()
+            times = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                root = m.search(BreakthroughGame(), add_noise=False)
+                _ = max(root.children.values(), key=lambda c: c.visit_count)
+                times.append(time.perf_counter() - t0)
+            lat[f"leaf_batch_{k}"] = {"ms_per_move": float(np.median(times)) * 1e3, "simulations": 200,
+                                      "us_per_simulation": float(np.median(times)) / 200 * 1e6}
+        lat["what"] = ("MCTS.search(start position, add_noise=False), 200 simulations, 20x128, median of 5; leaf_batch 1 is "
+                       "the reference's search bit for bit, leaf_batch 16 the opt-in leaf-parallel mode (other visit counts)")
+        out["latency_search"] = lat
+        del lat_model
+    except Exception as exc:
+        out["latency_search"] = {"error": repr(exc)}
     return out
 
 
